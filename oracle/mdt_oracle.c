@@ -1,0 +1,129 @@
+/*
+ * mdt_oracle.c -- CPU ORACLE for the ess / rhat / ess_rhat / rhat_nested / mcse(mean) hot path of
+ * MCMCDiagnosticTools.jl v0.3.19 (reference at /root/reference, Julia).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * `cpu_baseline` leg of bench.py may load it -- always as the checker, never as the thing that
+ * is measured or shipped.  The product library (libmdt_hip.so) does not link, load or call it.
+ *
+ * What it is: a statement-by-statement C restatement of
+ *     src/ess_rhat.jl:95-213 (autocov caches), :291-311 (ess kinds, tail), :350-420 (rhat kinds),
+ *     :456-624 (ess_rhat), :647-659 (quantile proxy);
+ *     src/utils.jl:13-41 (copyto_split!), :148-193 (fold, rank-normalise);
+ *     src/rhat_nested.jl:83-188; src/mcse.jl:45-51,
+ * plus the third-party behaviour those lines delegate to (none of it is under /root/reference:
+ * StatsBase 0.34 tiedrank, StatsFuns 1-2 norminvcdf, Statistics 1.6 median/quantile/var/mean,
+ * AbstractFFTs+FFTW fft; compat ranges from Project.toml:23-36, no Manifest), restated from the
+ * published algorithms as listed in SURVEY.md Appendix A.
+ *
+ * PARITY PINNING STATUS.  The reference cannot be run here (Julia absent) and its tests hold NO
+ * fixed numeric vectors for this path, so value-level parity at the third-party boundaries
+ * (tiedrank / norminvcdf / quantile / FFT outputs as numbers) is "parity unpinned" by reference
+ * output.  What IS pinned (tests/test_oracle_*.py):
+ *   - every known-answer test the reference's own suite holds for the path: antithetic-chain
+ *     ESS == ntotal*log10(ntotal) (test/ess_rhat.jl:314-327), constant input -> NaN
+ *     (:242-257), niter<=4 -> NaN ESS + valid R-hat (:66-98), relative scaling (:100-113),
+ *     bulk == basic o rank-normalise and monotone invariance (:329-335), FFT ~ direct,
+ *     R-hat identical across autocov methods (:210-240), copyto_split! row selection
+ *     (test/utils.jl:26-56), rank-normalise moments (:98-107), fold (:109-123),
+ *     rhat_nested ~ sqrt(rhat^2 + 1/D), permutation invariance, :rank == max(:bulk,:tail)
+ *     (test/rhat_nested.jl:113-155), mcse constant -> NaN (test/mcse.jl:86-101);
+ *   - an INDEPENDENT numpy/scipy restatement (oracle/numpy_oracle.py: scipy rankdata, ndtri,
+ *     numpy.fft, numpy.quantile) that must agree to <= 1e-10 on the golden inputs; the golden
+ *     vectors in tests/golden/ were minted from the two together (tests/golden/make_golden.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -shared).  Three instantiations of mdt_oracle_impl.inc:
+ *     _f64           T = double, arithmetic double   (the Float64 reference path)
+ *     _f32           T = float,  arithmetic double   ("f64-internal" comparator for the
+ *                                                     Float32 device path: rounds where the
+ *                                                     reference stores Float32, sums in double)
+ *     _f32_faithful  T = float,  arithmetic float    (what the reference does for Float32;
+ *                                                     reported, not gated on)
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct {
+    int64_t draws, chains, params; /* dense column-major x[d + draws*(c + chains*p)] */
+    int32_t kind;                  /* 0 basic, 1 bulk, 2 tail, 3 rank */
+    int32_t autocov;               /* 0 AutocovMethod, 1 FFTAutocovMethod, 2 BDAAutocovMethod */
+    int32_t split_chains;
+    int32_t relative;
+    int64_t maxlag;
+    double tail_prob;
+} mdt_oracle_args;
+
+/*
+ * StatsFuns.norminvcdf(p) = -erfcinv(2p)*sqrt(2) (call site src/utils.jl:182).  The upstream
+ * erfcinv is a ~1 ulp rational approximation whose source is not available here; any Phi^-1
+ * accurate to ~1e-16 meets the contract.  This one: Acklam's rational start (rel. err 1.2e-9)
+ * polished by two Halley steps on 0.5*erfc(-z/sqrt2) with libm erfc (<1 ulp) -- converges to
+ * the rounding floor.  The upper half is evaluated as -Phi^-1(1-p); 1-p is exact for p>=0.5.
+ */
+double mdt_oracle_norminvcdf(double p) {
+    if (isnan(p) || p < 0.0 || p > 1.0) return NAN;
+    if (p == 0.0) return -INFINITY;
+    if (p == 1.0) return INFINITY;
+    if (p > 0.5) return -mdt_oracle_norminvcdf(1.0 - p);
+    static const double a[6] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02,
+                                1.383577518672690e+02,  -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[5] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02,
+                                6.680131188771972e+01,  -1.328068155288572e+01};
+    static const double c[6] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00,
+                                -2.549732539343734e+00, 4.374664141464968e+00,  2.938163982698783e+00};
+    static const double d[4] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00,
+                                3.754408661907416e+00};
+    double z;
+    if (p < 0.02425) {
+        double q = sqrt(-2.0 * log(p));
+        z = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) /
+            ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1.0);
+    } else {
+        double q = p - 0.5, r = q * q;
+        z = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q /
+            (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1.0);
+    }
+    for (int it = 0; it < 2; ++it) {
+        double e = 0.5 * erfc(-z * M_SQRT1_2) - p;
+        double u = e * 2.5066282746310002 * exp(0.5 * z * z); /* sqrt(2*pi) */
+        z = z - u / (1.0 + 0.5 * z * u);
+    }
+    return z;
+}
+
+#define T double
+#define A double
+#define SFX _f64
+#define T_IS_DOUBLE 1
+#include "mdt_oracle_impl.inc"
+#undef T
+#undef A
+#undef SFX
+#undef T_IS_DOUBLE
+
+#define T float
+#define A double
+#define SFX _f32
+#define T_IS_DOUBLE 0
+#include "mdt_oracle_impl.inc"
+#undef T
+#undef A
+#undef SFX
+#undef T_IS_DOUBLE
+
+#define T float
+#define A float
+#define SFX _f32_faithful
+#define T_IS_DOUBLE 0
+#include "mdt_oracle_impl.inc"
+#undef T
+#undef A
+#undef SFX
+#undef T_IS_DOUBLE
