@@ -1,0 +1,132 @@
+/*
+ * mdt_hip.h -- C-ABI of libmdt_hip.so: the MI355X (gfx950) ESS / R-hat engine that stands behind
+ * MCMCDiagnosticTools.jl's ess / rhat / ess_rhat / rhat_nested / mcse(kind=mean).
+ *
+ * Boundary.  The reference is pure Julia and has no FFI for this path; the seam that is replaced
+ * is the set of exported functions themselves (SURVEY.md §8b "coarse seam").  A Julia shim
+ * (julia/MCMCDiagnosticToolsROC.jl) validates arguments exactly like the
+ * reference, flattens the parameter dimensions (src/utils.jl:197-215) and makes ONE ccall per
+ * request into the entry points below.  Each entry point cites the reference code it replaces
+ * (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - arrays are dense, column-major, shaped (draws, chains, params): x[d + draws*(c + chains*p)]
+ *     -- exactly the memory of a Julia Array{T,3}; outputs have `params` elements of dtype T;
+ *   - every function returns an int status: MDT_OK or one of the MDT_E* codes; the message for
+ *     the last failing call on a context is available from mdt_last_error();
+ *   - `location` says whether x / outputs are host pointers (the library stages them through its
+ *     own device buffers) or device pointers on the context's GPU (zero-copy; the hot path);
+ *   - a context is single-owner: one call at a time; distinct contexts may be used from distinct
+ *     host threads.  With `sync != 0` (what Julia wants: it reads the results immediately) the
+ *     call returns after the stream has drained; with `sync == 0` and device pointers the work
+ *     is only enqueued on `stream`;
+ *   - no exceptions cross the boundary; NaN inputs propagate as in the reference
+ *     (constant parameter -> NaN ESS and NaN R-hat, test/ess_rhat.jl:242-257).
+ */
+#ifndef MDT_HIP_H
+#define MDT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDT_VERSION 100 /* 0.1.0 */
+
+/* status codes (the Julia shim maps them to the reference's exception types) */
+#define MDT_OK 0
+#define MDT_EARG 1     /* ArgumentError   (src/ess_rhat.jl:286,294,347,453; src/rhat_nested.jl:49-79) */
+#define MDT_EDOMAIN 2  /* DomainError     (maxlag <= 0, src/ess_rhat.jl:481) */
+#define MDT_EDIM 3     /* DimensionMismatch (src/utils.jl:18-28, src/rhat_nested.jl:69-73) */
+#define MDT_ERUNTIME 4 /* HIP runtime error */
+#define MDT_ENOMEM 5   /* device or host allocation failed */
+#define MDT_EUNSUPPORTED 6 /* valid request the engine cannot serve (message says why) */
+
+/* dtype */
+#define MDT_F64 0
+#define MDT_F32 1
+/* location */
+#define MDT_HOST 0
+#define MDT_DEVICE 1
+/* kind: the `kind` keyword of ess / rhat / ess_rhat / rhat_nested (src/ess_rhat.jl:276-290,
+ * 335-349, 438-455; src/rhat_nested.jl:55-65) */
+#define MDT_KIND_BASIC 0
+#define MDT_KIND_BULK 1
+#define MDT_KIND_TAIL 2
+#define MDT_KIND_RANK 3
+/* outputs bitmask: ess() asks for ESS only, rhat() for RHAT only, ess_rhat() for both */
+#define MDT_OUT_ESS 1
+#define MDT_OUT_RHAT 2
+/* autocov: the AbstractAutocovMethod subtype (src/ess_rhat.jl:2,38,55,73) */
+#define MDT_AUTOCOV_DIRECT 0 /* AutocovMethod     (src/ess_rhat.jl:161-179) */
+#define MDT_AUTOCOV_FFT 1    /* FFTAutocovMethod  (src/ess_rhat.jl:103-118,130-152,181-195) */
+#define MDT_AUTOCOV_BDA 2    /* BDAAutocovMethod  (src/ess_rhat.jl:120-126,154-159,197-213) */
+
+typedef struct mdt_ctx mdt_ctx; /* opaque: device, scratch, normal-score tables */
+
+typedef struct mdt_args {
+    int64_t draws, chains, params; /* size(x, 1), size(x, 2), prod(size(x)[3:end]) */
+    int32_t dtype;                 /* MDT_F64 / MDT_F32: eltype of x and of the outputs */
+    int32_t location;              /* MDT_HOST / MDT_DEVICE for x and all outputs */
+    int32_t kind;                  /* MDT_KIND_* */
+    int32_t outputs;               /* MDT_OUT_ESS | MDT_OUT_RHAT (mdt_ess_rhat only) */
+    int32_t autocov;               /* MDT_AUTOCOV_* : keyword autocov_method */
+    int32_t split_chains;          /* keyword split_chains (default 2) */
+    int32_t relative;              /* keyword relative (default false) */
+    int32_t sync;                  /* nonzero: synchronise the stream before returning */
+    int64_t maxlag;                /* keyword maxlag (default 250) */
+    double tail_prob;              /* keyword tail_prob (default 1//10) */
+    void* stream;                  /* hipStream_t to enqueue on, or NULL for the default stream */
+} mdt_args;
+
+int mdt_version(void);
+
+/* context life cycle; device_id is the HIP device ordinal (one context per GPU per process) */
+int mdt_ctx_create(mdt_ctx** out, int device_id);
+int mdt_ctx_destroy(mdt_ctx* ctx);
+const char* mdt_last_error(const mdt_ctx* ctx);
+
+/*
+ * ess / rhat / ess_rhat  -- replaces src/ess_rhat.jl:276-311 (ess), :335-420 (rhat), :438-624
+ * (ess_rhat) together with the whole-array transforms they call (src/utils.jl:148-193) and the
+ * per-parameter kernels _rhat_basic! (:362-409) and _ess_rhat_basic! (:488-603).
+ * ess_out / rhat_out: [params] of dtype, or NULL when the corresponding bit of `outputs` is 0.
+ * niter = draws / split_chains <= 4 is NOT an error: ESS is filled with NaN and R-hat is still
+ * computed (src/ess_rhat.jl:472-479; the shim issues the @warn).  maxlag <= 0 with niter > 4
+ * and ESS requested -> MDT_EDOMAIN.
+ */
+int mdt_ess_rhat(mdt_ctx* ctx, const mdt_args* args, const void* x, void* ess_out, void* rhat_out);
+
+/*
+ * The BASELINE metric in one pass over x: ess_rhat(x; kind=:bulk) and ess_rhat(x; kind=:tail)
+ * fused (src/ess_rhat.jl:604-616), sharing the pooled ranking of x.  Any output may be NULL.
+ * rhat(kind=:rank) == max(rhat_bulk, rhat_tail) with Julia's NaN-propagating max (:416-420).
+ */
+int mdt_bulk_tail(mdt_ctx* ctx, const mdt_args* args, const void* x, void* ess_bulk, void* ess_tail,
+                  void* rhat_bulk, void* rhat_tail);
+
+/*
+ * rhat_nested -- replaces src/rhat_nested.jl:83-188.  chain_inds is what
+ * _validate_superchain_ids (:68-81) returns, made 0-based: a K x S column-major int32 matrix on
+ * the HOST whose column k lists the chains of the k-th superchain (K*S == chains, S >= 2).
+ */
+int mdt_rhat_nested(mdt_ctx* ctx, const mdt_args* args, const void* x, const int32_t* chain_inds,
+                    int32_t K, int32_t S, void* rhat_out);
+
+/* mcse(x; kind=Statistics.mean) -- replaces src/mcse.jl:45-51 (basic ESS, then pooled corrected
+ * std over all draws and chains divided by sqrt(ESS)).  args->kind is ignored. */
+int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
+
+/*
+ * Stage output for parity checks: _rank_normalize (src/utils.jl:169-184) of x (or, with
+ * fold != 0, of _fold_around_median(x), :148-158).  rank_out: [draws*chains*params] float64
+ * tied ranks (StatsBase.tiedrank) or NULL; z_out: same length, dtype, normal scores, or NULL.
+ */
+int mdt_rank_normalize(mdt_ctx* ctx, const mdt_args* args, const void* x, int32_t fold,
+                       double* rank_out, void* z_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDT_HIP_H */

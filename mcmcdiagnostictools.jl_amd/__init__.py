@@ -1,0 +1,22 @@
+"""MI355X-native ESS / R-hat engine behind MCMCDiagnosticTools.jl's ess / rhat / ess_rhat /
+rhat_nested / mcse(kind=mean) API (reference: src/MCMCDiagnosticTools.jl:17-25 exports).
+
+The directory name contains a dot, so import it through `__graft_entry__.load_package()`
+(module name `mcmcdiagnostictools_jl_amd`).
+"""
+from ._lib import ArgumentError, DimensionMismatch, DomainError, MdtRuntimeError  # noqa: F401
+from .api import (  # noqa: F401
+    AbstractAutocovMethod,
+    AutocovMethod,
+    BDAAutocovMethod,
+    ESSRhat,
+    FFTAutocovMethod,
+    bulk_tail,
+    ess,
+    ess_rhat,
+    mcse,
+    rank_normalize,
+    rhat,
+    rhat_nested,
+)
+from .dist import ess_rhat_sharded, shard_bounds  # noqa: F401

@@ -1,0 +1,117 @@
+"""ctypes binding of csrc/libmdt_hip.so (the C-ABI declared in include/mdt_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible, every compute
+entry point raises.  Build with `python -c "import __graft_entry__ as g; g.build()"`.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmdt_hip.so")
+
+MDT_OK, MDT_EARG, MDT_EDOMAIN, MDT_EDIM, MDT_ERUNTIME, MDT_ENOMEM, MDT_EUNSUPPORTED = range(7)
+MDT_F64, MDT_F32 = 0, 1
+MDT_HOST, MDT_DEVICE = 0, 1
+KIND = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3}
+OUT_ESS, OUT_RHAT = 1, 2
+
+# every symbol include/mdt_hip.h declares
+SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_destroy", "mdt_last_error", "mdt_ess_rhat",
+           "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_rank_normalize")
+
+
+class MdtArgs(ctypes.Structure):
+    _fields_ = [
+        ("draws", ctypes.c_int64),
+        ("chains", ctypes.c_int64),
+        ("params", ctypes.c_int64),
+        ("dtype", ctypes.c_int32),
+        ("location", ctypes.c_int32),
+        ("kind", ctypes.c_int32),
+        ("outputs", ctypes.c_int32),
+        ("autocov", ctypes.c_int32),
+        ("split_chains", ctypes.c_int32),
+        ("relative", ctypes.c_int32),
+        ("sync", ctypes.c_int32),
+        ("maxlag", ctypes.c_int64),
+        ("tail_prob", ctypes.c_double),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+class ArgumentError(ValueError):
+    """Julia's ArgumentError (MDT_EARG)."""
+
+
+class DomainError(ValueError):
+    """Julia's DomainError (MDT_EDOMAIN), e.g. maxlag <= 0 (src/ess_rhat.jl:481)."""
+
+
+class DimensionMismatch(ValueError):
+    """Julia's DimensionMismatch (MDT_EDIM)."""
+
+
+class MdtRuntimeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; loud failure when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdtRuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run __graft_entry__.build()); there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+        ap = ctypes.POINTER(MdtArgs)
+        lib.mdt_version.restype = ctypes.c_int
+        lib.mdt_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+        lib.mdt_ctx_destroy.argtypes = [vp]
+        lib.mdt_last_error.argtypes = [vp]
+        lib.mdt_last_error.restype = ctypes.c_char_p
+        lib.mdt_ess_rhat.argtypes = [vp, ap, vp, vp, vp]
+        lib.mdt_bulk_tail.argtypes = [vp, ap, vp, vp, vp, vp, vp]
+        lib.mdt_rhat_nested.argtypes = [vp, ap, vp, vp, i32, i32, vp]
+        lib.mdt_mcse_mean.argtypes = [vp, ap, vp, vp]
+        lib.mdt_rank_normalize.argtypes = [vp, ap, vp, i32, vp, vp]
+        _ = i64
+        _lib = lib
+    return _lib
+
+
+_ctxs = {}
+
+
+def ctx(device):
+    """one mdt_ctx per GPU per process"""
+    lib = load()
+    if device not in _ctxs:
+        h = ctypes.c_void_p()
+        rc = lib.mdt_ctx_create(ctypes.byref(h), int(device))
+        if rc != MDT_OK:
+            raise MdtRuntimeError(f"mdt_ctx_create(device={device}) failed with status {rc} "
+                                  "(no MI355X visible? there is no CPU fallback)")
+        _ctxs[device] = h
+    return _ctxs[device]
+
+
+def check(rc, h):
+    if rc == MDT_OK:
+        return
+    msg = load().mdt_last_error(h).decode()
+    if rc == MDT_EARG:
+        raise ArgumentError(msg)
+    if rc == MDT_EDOMAIN:
+        raise DomainError(msg)
+    if rc == MDT_EDIM:
+        raise DimensionMismatch(msg)
+    if rc == MDT_EUNSUPPORTED:
+        raise NotImplementedError(msg)
+    if rc == MDT_ENOMEM:
+        raise MemoryError(msg)
+    raise MdtRuntimeError(f"status {rc}: {msg}")

@@ -1,0 +1,343 @@
+"""Host-side mirror of the reference's operator interface for the hot path.
+
+Same names, keyword meaning and error behaviour as MCMCDiagnosticTools.jl (the reference is Julia;
+Julia is not in this image, so the tested host side is Python and the Julia shim in julia/ is the
+thin ccall layer a maintainer would ship -- INTEGRATION.md):
+
+    ess(samples; kind=:bulk, relative=false, autocov_method=AutocovMethod(), split_chains=2,
+        maxlag=250, tail_prob=1//10)                      src/ess_rhat.jl:276-311
+    rhat(samples; kind=:rank, split_chains=2)             src/ess_rhat.jl:335-420
+    ess_rhat(samples; kind=:rank, kwargs...)              src/ess_rhat.jl:438-624
+    rhat_nested(samples, superchain_ids; kind, split_chains)   src/rhat_nested.jl:43-125
+    mcse(samples; kind=mean, kwargs...)                   src/mcse.jl:40-51
+
+`samples` has shape (draws, [chains, [parameters...]]) -- the reference's array convention.  It may
+be a torch tensor on the GPU (zero-copy when its memory is draws-fastest, i.e. it was built as
+a (params, chains, draws) tensor and permuted), a CPU tensor or a numpy array (staged through the
+library's device buffers).  All compute happens in libmdt_hip.so; nothing here computes a
+diagnostic on the CPU.
+"""
+import ctypes
+import statistics
+import warnings
+from collections import namedtuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import ArgumentError, DimensionMismatch
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class AbstractAutocovMethod:
+    """src/ess_rhat.jl:2"""
+    _code = None
+
+
+class AutocovMethod(AbstractAutocovMethod):
+    """src/ess_rhat.jl:38 -- direct lagged dot products (the default)."""
+    _code = 0
+
+
+class FFTAutocovMethod(AbstractAutocovMethod):
+    """src/ess_rhat.jl:55"""
+    _code = 1
+
+
+class BDAAutocovMethod(AbstractAutocovMethod):
+    """src/ess_rhat.jl:73 -- variogram estimator"""
+    _code = 2
+
+
+ESSRhat = namedtuple("ESSRhat", ["ess", "rhat"])  # NamedTuple{(:ess, :rhat)}
+
+_KINDS = ("rank", "bulk", "tail", "basic")
+
+
+def _norm_kind(kind):
+    if isinstance(kind, str):
+        return kind[1:] if kind.startswith(":") else kind
+    return kind
+
+
+def _is_mean(f):
+    return f is np.mean or f is statistics.mean or f is statistics.fmean or (
+        torch is not None and f is torch.mean) or f == "mean"
+
+
+class _Prepared:
+    """samples flattened to (draws, chains, params) with draws-fastest memory"""
+    pass
+
+
+def _prepare(samples):
+    pr = _Prepared()
+    mask = None
+    if isinstance(samples, np.ma.MaskedArray):  # the reference's Union{Missing,T} eltype
+        mask = np.ma.getmaskarray(samples)
+        samples = samples.filled(0.0)
+    is_torch = torch is not None and isinstance(samples, torch.Tensor)
+    if not is_torch:
+        samples = np.asarray(samples)
+        if samples.dtype not in (np.float32, np.float64):
+            samples = samples.astype(np.float64)  # promote_type(eltype, typeof(zero/1))
+    else:
+        if samples.dtype not in (torch.float32, torch.float64):
+            samples = samples.to(torch.float64 if not samples.dtype.is_floating_point else torch.float32)
+    if samples.ndim < 1:
+        raise ArgumentError("`samples` must have at least 1 dimension")
+    shape = tuple(samples.shape)
+    pr.orig_shape = shape
+    pr.param_shape = shape[2:]
+    pr.scalar = len(shape) < 3  # _maybescalar (src/utils.jl:214-215)
+    D = shape[0]
+    C = shape[1] if len(shape) > 1 else 1
+    P = 1
+    for d in pr.param_shape:
+        P *= d
+    pr.D, pr.C, pr.P = D, C, P
+    x3 = samples.reshape(D, C, P)
+    if is_torch:
+        xt = x3.permute(2, 1, 0).contiguous()  # no copy when memory is already draws-fastest
+        pr.dev = xt.is_cuda
+        pr.device_index = xt.device.index if xt.is_cuda else 0
+        pr.buf = xt
+        pr.ptr = xt.data_ptr()
+        pr.f32 = xt.dtype == torch.float32
+        pr.torch = True
+        pr.like = samples
+    else:
+        xt = np.ascontiguousarray(np.transpose(x3, (2, 1, 0)))
+        pr.dev = False
+        pr.device_index = 0
+        pr.buf = xt
+        pr.ptr = xt.ctypes.data
+        pr.f32 = xt.dtype == np.float32
+        pr.torch = False
+        pr.like = None
+    pr.missing = None
+    if mask is not None:
+        pr.missing = mask.reshape(D, C, P).any(axis=(0, 1))
+    return pr
+
+
+def _new_out(pr, n=None, dtype=None):
+    n = pr.P if n is None else n
+    if pr.torch:
+        dt = dtype or (torch.float32 if pr.f32 else torch.float64)
+        return torch.empty(n, dtype=dt, device=pr.buf.device)
+    dt = dtype or (np.float32 if pr.f32 else np.float64)
+    return np.empty(n, dtype=dt)
+
+
+def _optr(o):
+    if o is None:
+        return None
+    return o.data_ptr() if (torch is not None and isinstance(o, torch.Tensor)) else o.ctypes.data
+
+
+def _args(pr, kind, outputs, autocov, split_chains, maxlag, relative, tail_prob, sync=True):
+    stream = None
+    if pr.dev:
+        stream = torch.cuda.current_stream(pr.buf.device).cuda_stream
+    return _lib.MdtArgs(pr.D, pr.C, pr.P, _lib.MDT_F32 if pr.f32 else _lib.MDT_F64,
+                        _lib.MDT_DEVICE if pr.dev else _lib.MDT_HOST, kind, outputs, autocov, int(split_chains),
+                        1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream)
+
+
+def _finish(pr, out):
+    """param axes, Missing and scalar conventions of the reference (src/utils.jl:197-215)"""
+    if out is None:
+        return None
+    if pr.missing is not None:
+        arr = out.cpu().numpy() if pr.torch else out
+        arr = np.ma.MaskedArray(arr.reshape(pr.param_shape), mask=pr.missing.reshape(pr.param_shape))
+        return arr if not pr.scalar else (np.ma.masked if pr.missing.any() else float(arr))
+    if pr.scalar:
+        return float(out[0])
+    return out.reshape(pr.param_shape)
+
+
+def _autocov_code(m):
+    if isinstance(m, AbstractAutocovMethod) and m._code is not None:
+        return m._code
+    if isinstance(m, type) and issubclass(m, AbstractAutocovMethod) and m._code is not None:
+        return m._code
+    raise ArgumentError(
+        "autocov_method must be AutocovMethod(), FFTAutocovMethod() or BDAAutocovMethod(); "
+        "user-defined AbstractAutocovMethod plugins run on the reference's CPU path only")
+
+
+def _check_int(name, v):
+    if isinstance(v, bool) or not isinstance(v, (int, np.integer)):
+        raise TypeError(f"`{name}` must be an integer")  # Julia: MethodError on ::Int keyword
+    return int(v)
+
+
+def _warn_niter(pr, split_chains):
+    niter = pr.D // split_chains
+    if not niter > 4:  # src/ess_rhat.jl:472-479
+        warnings.warn(f"number of draws after splitting must be >4 but is {niter}. ESS cannot be computed.")
+
+
+def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_method=None, split_chains=2,
+                   maxlag=250, tail_prob=0.1, sync=True):
+    split_chains = _check_int("split_chains", split_chains)
+    maxlag = _check_int("maxlag", maxlag)
+    if split_chains < 1:
+        raise ArgumentError("split_chains must be >= 1")
+    autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
+    pr = _prepare(samples)
+    if want_ess:
+        _warn_niter(pr, split_chains)
+    ess_o = _new_out(pr) if want_ess else None
+    rhat_o = _new_out(pr) if want_rhat else None
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, _lib.KIND[kind], (1 if want_ess else 0) | (2 if want_rhat else 0), autocov, split_chains,
+                  maxlag, relative, tail_prob, sync)
+        rc = _lib.load().mdt_ess_rhat(h, ctypes.byref(a), pr.ptr, _optr(ess_o), _optr(rhat_o))
+        _lib.check(rc, h)
+    return pr, ess_o, rhat_o
+
+
+def ess(samples, *, kind="bulk", **kwargs):
+    """Effective sample size (src/ess_rhat.jl:276-311).  `kind` is "bulk", "tail", "basic" or an
+    estimator; of the estimators only the mean proxy (`numpy.mean`) is on the device path
+    (src/ess_rhat.jl:629), the others are listed as next in SURVEY.md §8f."""
+    kind = _norm_kind(kind)
+    if kind in ("bulk", "tail", "basic"):
+        pr, e, _ = _call_ess_rhat(samples, kind, True, False, **kwargs)
+        return _finish(pr, e)
+    if isinstance(kind, str):
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `ess`")
+    if _is_mean(kind):
+        kwargs.pop("tail_prob", None)
+        pr, e, _ = _call_ess_rhat(samples, "basic", True, False, **kwargs)
+        return _finish(pr, e)
+    if kind in (np.median, np.std, statistics.median):
+        raise NotImplementedError(f"the estimator {kind} is not on the device path yet (SURVEY.md §8f)")
+    raise ArgumentError(f"the estimator {kind} is not yet supported by `ess`")
+
+
+def rhat(samples, *, kind="rank", split_chains=2):
+    """R-hat (src/ess_rhat.jl:335-420)."""
+    kind = _norm_kind(kind)
+    if kind not in _KINDS:
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat`")
+    pr, _, r = _call_ess_rhat(samples, kind, False, True, split_chains=split_chains)
+    return _finish(pr, r)
+
+
+def ess_rhat(samples, *, kind="rank", **kwargs):
+    """(ess=..., rhat=...) (src/ess_rhat.jl:438-624)."""
+    kind = _norm_kind(kind)
+    if kind not in _KINDS:
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `ess_rhat`")
+    pr, e, r = _call_ess_rhat(samples, kind, True, True, **kwargs)
+    return ESSRhat(_finish(pr, e), _finish(pr, r))
+
+
+def bulk_tail(samples, *, relative=False, autocov_method=None, split_chains=2, maxlag=250, tail_prob=0.1,
+              sync=True, out=None):
+    """The BASELINE metric in one pass: ess_rhat(kind=:bulk) and ess_rhat(kind=:tail) fused.
+    Returns (ess_bulk, ess_tail, rhat_bulk, rhat_tail)."""
+    split_chains = _check_int("split_chains", split_chains)
+    maxlag = _check_int("maxlag", maxlag)
+    autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
+    pr = _prepare(samples)
+    _warn_niter(pr, split_chains)
+    outs = out if out is not None else [_new_out(pr) for _ in range(4)]
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, 0, 3, autocov, split_chains, maxlag, relative, tail_prob, sync)
+        rc = _lib.load().mdt_bulk_tail(h, ctypes.byref(a), pr.ptr, *[_optr(o) for o in outs])
+        _lib.check(rc, h)
+    if out is not None:
+        return out
+    return tuple(_finish(pr, o) for o in outs)
+
+
+def _validate_superchain_ids(superchain_ids, nchains):
+    """src/rhat_nested.jl:68-81 + unique_indices (src/utils.jl:50-64): K x S, 0-based"""
+    ids = list(superchain_ids)
+    if len(ids) != nchains:
+        raise DimensionMismatch(f"`superchain_ids` has length {len(ids)} but `samples` has {nchains} chains")
+    groups = {}
+    for i, v in enumerate(ids):
+        groups.setdefault(v, []).append(i)
+    keys = sorted(groups)  # SortedDict order
+    if len(keys) < 2:
+        raise ArgumentError(f"at least 2 superchains are required, got {len(keys)}")
+    sizes = {len(groups[k]) for k in keys}
+    if len(sizes) != 1:
+        raise ArgumentError("all superchains must contain the same number of chains")
+    return np.asfortranarray(np.array([groups[k] for k in keys], dtype=np.int32).T)
+
+
+def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
+    """Nested R-hat (src/rhat_nested.jl:43-188)."""
+    nd = samples.ndim if hasattr(samples, "ndim") else np.asarray(samples).ndim
+    if nd < 2:
+        raise ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`")
+    split_chains = _check_int("split_chains", split_chains)
+    inds = _validate_superchain_ids(superchain_ids, samples.shape[1])
+    kind = _norm_kind(kind)
+    if kind not in _KINDS:
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat_nested`")
+    pr = _prepare(samples)
+    out = _new_out(pr)
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, _lib.KIND[kind], 2, 0, split_chains, 250, False, 0.1)
+        K, S = inds.shape
+        rc = _lib.load().mdt_rhat_nested(h, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(out))
+        _lib.check(rc, h)
+    return _finish(pr, out)
+
+
+def mcse(samples, *, kind=np.mean, **kwargs):
+    """Monte Carlo standard error; only kind=mean is on the device path (src/mcse.jl:45-51)."""
+    if not _is_mean(kind):
+        raise NotImplementedError("only mcse(kind=mean) is on the device path (SURVEY.md §8f)")
+    split_chains = _check_int("split_chains", kwargs.pop("split_chains", 2))
+    maxlag = _check_int("maxlag", kwargs.pop("maxlag", 250))
+    autocov = _autocov_code(kwargs.pop("autocov_method", AutocovMethod()))
+    relative = kwargs.pop("relative", False)
+    if kwargs:
+        raise TypeError(f"unsupported keyword arguments {sorted(kwargs)}")
+    pr = _prepare(samples)
+    _warn_niter(pr, split_chains)
+    out = _new_out(pr)
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
+        rc = _lib.load().mdt_mcse_mean(h, ctypes.byref(a), pr.ptr, _optr(out))
+        _lib.check(rc, h)
+    return _finish(pr, out)
+
+
+def rank_normalize(samples, *, fold=False, want_ranks=True):
+    """Stage output: (tied ranks as float64, normal scores) of `_rank_normalize(samples)` or of
+    `_rank_normalize(_fold_around_median(samples))` (src/utils.jl:148-184); shape of `samples`."""
+    pr = _prepare(samples)
+    n = pr.D * pr.C * pr.P
+    ranks = _new_out(pr, n, (torch.float64 if pr.torch else np.float64)) if want_ranks else None
+    z = _new_out(pr, n)
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
+        rc = _lib.load().mdt_rank_normalize(h, ctypes.byref(a), pr.ptr, 1 if fold else 0, _optr(ranks), _optr(z))
+        _lib.check(rc, h)
+
+    def back(o):
+        if o is None:
+            return None
+        o3 = o.reshape(pr.P, pr.C, pr.D)
+        o3 = o3.permute(2, 1, 0) if pr.torch else np.transpose(o3, (2, 1, 0))
+        return o3.reshape(pr.orig_shape)
+    return back(ranks), back(z)

@@ -1,0 +1,399 @@
+// mdt_hip.hip -- C-ABI of libmdt_hip.so (see include/mdt_hip.h) around the kernels in
+// mdt_device.hpp.  Host responsibilities: argument validation with the reference's error
+// behaviour, evaluation of the few scalars the reference computes in eltype(x) (log10(ntotal),
+// the type-7 quantile index and gamma), scratch and normal-score-table management, launch.
+//
+// Build (see __graft_entry__.build / csrc/Makefile):
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC -I include -o libmdt_hip.so mdt_hip.hip
+// -ffp-contract=off: the scalar formulas that mirror Julia expressions (quantile, median,
+// var+, tau) must round like Julia does; hot loops use explicit fma().
+#include "mdt_device.hpp"
+#include "mdt_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+using namespace mdt;
+
+struct mdt_ctx {
+    int device = 0;
+    int num_cu = 0;
+    int grid = 0;
+    std::string err;
+    // per-workgroup scratch
+    unsigned int* r2buf = nullptr;
+    unsigned short* binbuf = nullptr;
+    long long n_pad = 0;
+    // normal-score table
+    double* ztab = nullptr;
+    long long ztab_n = -1;
+    int ztab_f32 = -1;
+    long long ztab_cap = 0;
+    // status word + nested chain indices
+    int* status = nullptr;
+    int* chain_inds = nullptr;
+    int chain_inds_cap = 0;
+    // host staging
+    void* stage_x = nullptr;
+    size_t stage_x_cap = 0;
+    void* stage_out = nullptr;
+    size_t stage_out_cap = 0;
+};
+
+namespace {
+
+int fail(mdt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? MDT_ENOMEM : MDT_ERUNTIME,            \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+size_t tsize(int dtype) { return dtype == MDT_F32 ? 4 : 8; }
+
+int ensure_scratch(mdt_ctx* ctx, long long n) {
+    const long long n_pad = ((n + 63) / 64) * 64;
+    if (n_pad > ctx->n_pad) {
+        if (ctx->r2buf) (void)hipFree(ctx->r2buf);
+        if (ctx->binbuf) (void)hipFree(ctx->binbuf);
+        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->n_pad = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)ctx->grid * n_pad * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
+        ctx->n_pad = n_pad;
+    }
+    return MDT_OK;
+}
+
+int ensure_ztab(mdt_ctx* ctx, long long n, int f32, hipStream_t st) {
+    if (ctx->ztab_n == n && ctx->ztab_f32 == f32) return MDT_OK;
+    const long long need = 2 * n + 1;
+    if (need > ctx->ztab_cap) {
+        if (ctx->ztab) (void)hipFree(ctx->ztab);
+        ctx->ztab = nullptr; ctx->ztab_cap = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->ztab, (size_t)need * sizeof(double)));
+        ctx->ztab_cap = need;
+    }
+    const int bs = 256;
+    const long long nb = (need + bs - 1) / bs;
+    hipLaunchKernelGGL(ztab_kernel, dim3((unsigned)nb), dim3(bs), 0, st, ctx->ztab, n, f32);
+    HIP_TRY(hipGetLastError());
+    ctx->ztab_n = n;
+    ctx->ztab_f32 = f32;
+    return MDT_OK;
+}
+
+// what a request needs, common to all entry points
+struct Req {
+    int mode = 0;
+    int basic = 0;
+    int need_eb = 0, need_rb = 0, need_et = 0, need_rt = 0;
+    void* out_eb = nullptr; void* out_rb = nullptr; void* out_et = nullptr; void* out_rt = nullptr;
+    void* out_rrank = nullptr;
+    double* rank_out = nullptr; void* z_out = nullptr;
+    int fold = 0;
+    const int32_t* chain_inds = nullptr; int K = 0, S = 0;
+    int want_ess = 0; // ESS of some kind is requested (drives the maxlag domain check)
+};
+
+int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
+    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    if (a->split_chains < 1) return fail(ctx, MDT_EARG, "split_chains must be >= 1");
+    if (a->autocov < 0 || a->autocov > 2) return fail(ctx, MDT_EARG, "unknown autocov method");
+    const long long D = a->draws, C = a->chains, P = a->params, s = a->split_chains;
+    if (P == 0) return MDT_OK;
+    if (!x) return fail(ctx, MDT_EARG, "x is NULL");
+    if (D == 0 || C == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+    const long long n = D * C, niter = D / s, m = C * s;
+    const int ess_ok = niter > 4;
+    long long maxlag = a->maxlag;
+    if (rq.want_ess && ess_ok) {
+        if (!(maxlag > 0)) return fail(ctx, MDT_EDOMAIN, "maxlag must be >0."); // src/ess_rhat.jl:481
+        if (maxlag > niter - 4) maxlag = niter - 4;                              // :482
+    } else {
+        maxlag = 1;
+    }
+    if (!(a->tail_prob > 0.0 && a->tail_prob < 1.0) && rq.need_et) return fail(ctx, MDT_EARG, "tail_prob must be in (0, 1)");
+    // engine limits
+    if (m > MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
+    if (maxlag > MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
+    if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
+    if (rq.need_et && D > (long long)BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 262144 not supported for tail ESS");
+    if (a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok)
+        return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod is not implemented on the device yet");
+
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)a->stream;
+    const size_t ts = tsize(a->dtype);
+    const bool f32 = a->dtype == MDT_F32;
+
+    // host staging
+    const void* dx = x;
+    void* outs_host[5] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank};
+    void* outs_dev[5] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank};
+    double* rank_host = rq.rank_out; void* z_host = rq.z_out;
+    if (a->location == MDT_HOST) {
+        const size_t xb = (size_t)n * P * ts;
+        if (xb > ctx->stage_x_cap) {
+            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
+            ctx->stage_x_cap = xb;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
+        dx = ctx->stage_x;
+        size_t ob = 5 * (size_t)P * ts;
+        if (rq.mode == 3) ob += (size_t)n * P * (8 + ts);
+        if (ob > ctx->stage_out_cap) {
+            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+            ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->stage_out, ob));
+            ctx->stage_out_cap = ob;
+        }
+        for (int i = 0; i < 5; ++i)
+            outs_dev[i] = outs_host[i] ? (void*)((char*)ctx->stage_out + (size_t)i * P * ts) : nullptr;
+        if (rq.mode == 3) {
+            char* base = (char*)ctx->stage_out + 5 * (size_t)P * ts;
+            base = (char*)(((uintptr_t)base + 15) & ~(uintptr_t)15);
+            if (rank_host) rq.rank_out = (double*)base;
+            if (z_host) rq.z_out = base + (size_t)n * P * 8;
+        }
+    }
+
+    int rc = ensure_scratch(ctx, n);
+    if (rc) return rc;
+    const bool need_rank = !rq.basic || rq.mode == 3;
+    if (need_rank) {
+        rc = ensure_ztab(ctx, n, f32 ? 1 : 0, st);
+        if (rc) return rc;
+    }
+    if (rq.mode == 1) {
+        const int cnt = rq.K * rq.S;
+        if (cnt > ctx->chain_inds_cap) {
+            if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
+            ctx->chain_inds = nullptr; ctx->chain_inds_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->chain_inds, (size_t)cnt * sizeof(int)));
+            ctx->chain_inds_cap = cnt;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->chain_inds, rq.chain_inds, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(int), st));
+
+    KP kp;
+    memset(&kp, 0, sizeof(kp));
+    kp.x = dx;
+    kp.D = D; kp.C = C; kp.P = P; kp.n = n;
+    kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
+    kp.mode = rq.mode; kp.basic = rq.basic;
+    kp.need_eb = rq.need_eb; kp.need_rb = rq.need_rb; kp.need_et = rq.need_et; kp.need_rt = rq.need_rt;
+    kp.method = a->autocov; kp.ess_ok = ess_ok; kp.relative = a->relative ? 1 : 0; kp.fold = rq.fold;
+    kp.maxlag = maxlag;
+    const long long ntotal = niter * m;
+    // rel_ess_max = log10(oftype(one(T), ntotal)) evaluated in T (src/ess_rhat.jl:514)
+    kp.rel_ess_max = f32 ? (double)log10f((float)ntotal) : log10((double)ntotal);
+    kp.ntotal = (double)ntotal;
+    kp.cf = niter > 0 ? (double)(niter - 1) / (double)niter : -INFINITY; // (niter - 1)//niter
+    // type-7 quantile index/gamma in T (Statistics.quantile: aleph = fma(n, p, 1 - p)), :305-309
+    for (int i = 0; i < 2; ++i) {
+        long long j; double g;
+        if (f32) {
+            const float p = (i == 0) ? (float)(a->tail_prob / 2) : (float)(1 - a->tail_prob / 2);
+            const float aleph = fmaf((float)n, p, 1.0f - p);
+            j = (long long)aleph;
+            if (j < 1) j = 1;
+            if (j > n - 1) j = n - 1;
+            float gg = aleph - (float)j;
+            gg = gg < 0 ? 0 : (gg > 1 ? 1 : gg);
+            g = (double)gg;
+        } else {
+            const double p = (i == 0) ? (a->tail_prob / 2) : (1 - a->tail_prob / 2);
+            const double aleph = fma((double)n, p, 1.0 - p);
+            j = (long long)aleph;
+            if (j < 1) j = 1;
+            if (j > n - 1) j = n - 1;
+            g = aleph - (double)j;
+            g = g < 0 ? 0 : (g > 1 ? 1 : g);
+        }
+        if (n == 1) j = 1;
+        kp.q_j[i] = j;
+        kp.q_g[i] = g;
+    }
+    kp.ztab = ctx->ztab;
+    kp.r2buf = ctx->r2buf; kp.binbuf = ctx->binbuf; kp.n_pad = ctx->n_pad;
+    kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
+    kp.out_rrank = outs_dev[4];
+    kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
+    kp.chain_inds = ctx->chain_inds; kp.K = rq.K; kp.S = rq.S;
+    kp.status = ctx->status;
+
+    const unsigned grid = (unsigned)((P < ctx->grid) ? P : ctx->grid);
+    if (f32)
+        hipLaunchKernelGGL(mdt_kernel<float>, dim3(grid), dim3(NT), LDS_BYTES, st, kp);
+    else
+        hipLaunchKernelGGL(mdt_kernel<double>, dim3(grid), dim3(NT), LDS_BYTES, st, kp);
+    HIP_TRY(hipGetLastError());
+
+    if (a->location == MDT_HOST) {
+        for (int i = 0; i < 5; ++i)
+            if (outs_host[i]) HIP_TRY(hipMemcpyAsync(outs_host[i], outs_dev[i], (size_t)P * ts, hipMemcpyDeviceToHost, st));
+        if (rq.mode == 3) {
+            if (rank_host) HIP_TRY(hipMemcpyAsync(rank_host, rq.rank_out, (size_t)n * P * 8, hipMemcpyDeviceToHost, st));
+            if (z_host) HIP_TRY(hipMemcpyAsync(z_host, rq.z_out, (size_t)n * P * ts, hipMemcpyDeviceToHost, st));
+        }
+    }
+    if (a->sync || a->location == MDT_HOST) {
+        int status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (status & 1) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
+        if (status & 2) return fail(ctx, MDT_EARG, "quantiles are undefined for collections containing NaNs"); // Statistics.quantile
+    }
+    return MDT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mdt_version(void) { return MDT_VERSION; }
+
+int mdt_ctx_create(mdt_ctx** out, int device_id) {
+    if (!out) return MDT_EARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return MDT_ERUNTIME;
+    if (device_id < 0 || device_id >= ndev) return MDT_EARG;
+    mdt_ctx* ctx = new (std::nothrow) mdt_ctx();
+    if (!ctx) return MDT_ENOMEM;
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->grid = ctx->num_cu > 0 ? ctx->num_cu : 256; // one 1024-thread workgroup per CU (LDS-bound)
+    if (hipMalloc((void**)&ctx->status, sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
+    // > 64 KB of dynamic LDS needs the opt-in
+    if (hipFuncSetAttribute((const void*)mdt_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mdt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        (void)hipFree(ctx->status);
+        delete ctx;
+        return MDT_ERUNTIME;
+    }
+    *out = ctx;
+    return MDT_OK;
+}
+
+int mdt_ctx_destroy(mdt_ctx* ctx) {
+    if (!ctx) return MDT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->r2buf) (void)hipFree(ctx->r2buf);
+    if (ctx->binbuf) (void)hipFree(ctx->binbuf);
+    if (ctx->ztab) (void)hipFree(ctx->ztab);
+    if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
+    if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+    if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    delete ctx;
+    return MDT_OK;
+}
+
+const char* mdt_last_error(const mdt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mdt_ess_rhat(mdt_ctx* ctx, const mdt_args* a, const void* x, void* ess_out, void* rhat_out) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    const int want_ess = (a->outputs & MDT_OUT_ESS) != 0, want_rhat = (a->outputs & MDT_OUT_RHAT) != 0;
+    if (!want_ess && !want_rhat) return fail(ctx, MDT_EARG, "outputs selects nothing");
+    if ((want_ess && !ess_out) || (want_rhat && !rhat_out)) return fail(ctx, MDT_EARG, "requested output pointer is NULL");
+    Req rq;
+    rq.want_ess = want_ess;
+    switch (a->kind) {
+    case MDT_KIND_BASIC:
+        rq.basic = 1; rq.need_eb = want_ess; rq.need_rb = want_rhat;
+        rq.out_eb = want_ess ? ess_out : nullptr; rq.out_rb = want_rhat ? rhat_out : nullptr;
+        break;
+    case MDT_KIND_BULK:
+        rq.need_eb = want_ess; rq.need_rb = want_rhat;
+        rq.out_eb = want_ess ? ess_out : nullptr; rq.out_rb = want_rhat ? rhat_out : nullptr;
+        break;
+    case MDT_KIND_TAIL:
+        rq.need_et = want_ess; rq.need_rt = want_rhat;
+        rq.out_et = want_ess ? ess_out : nullptr; rq.out_rt = want_rhat ? rhat_out : nullptr;
+        break;
+    case MDT_KIND_RANK: // ess = bulk ESS, rhat = max(rhat_tail, rhat_bulk)  (src/ess_rhat.jl:617-624)
+        rq.need_eb = want_ess; rq.need_rb = want_rhat; rq.need_rt = want_rhat;
+        rq.out_eb = want_ess ? ess_out : nullptr; rq.out_rrank = want_rhat ? rhat_out : nullptr;
+        break;
+    default:
+        return fail(ctx, MDT_EARG, "the `kind` is not supported"); // src/ess_rhat.jl:286,347,453
+    }
+    return run(ctx, a, x, rq);
+}
+
+int mdt_bulk_tail(mdt_ctx* ctx, const mdt_args* a, const void* x, void* ess_bulk, void* ess_tail,
+                  void* rhat_bulk, void* rhat_tail) {
+    if (!ctx) return MDT_EARG;
+    Req rq;
+    rq.need_eb = ess_bulk != nullptr; rq.need_et = ess_tail != nullptr;
+    rq.need_rb = rhat_bulk != nullptr; rq.need_rt = rhat_tail != nullptr;
+    rq.out_eb = ess_bulk; rq.out_et = ess_tail; rq.out_rb = rhat_bulk; rq.out_rt = rhat_tail;
+    rq.want_ess = rq.need_eb || rq.need_et;
+    if (!(rq.need_eb || rq.need_et || rq.need_rb || rq.need_rt)) return fail(ctx, MDT_EARG, "all outputs are NULL");
+    return run(ctx, a, x, rq);
+}
+
+int mdt_rhat_nested(mdt_ctx* ctx, const mdt_args* a, const void* x, const int32_t* chain_inds,
+                    int32_t K, int32_t S, void* rhat_out) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (!chain_inds || !rhat_out) return fail(ctx, MDT_EARG, "NULL pointer");
+    if (S < 2) return fail(ctx, MDT_EARG, "at least 2 superchains are required"); // src/rhat_nested.jl:76-77
+    if (K < 1 || (long long)K * S != a->chains)
+        return fail(ctx, MDT_EDIM, "`superchain_ids` does not cover the chains of `samples`"); // :69-73
+    for (int i = 0; i < K * S; ++i)
+        if (chain_inds[i] < 0 || chain_inds[i] >= a->chains) return fail(ctx, MDT_EARG, "chain index out of range");
+    Req rq;
+    rq.mode = 1;
+    rq.chain_inds = chain_inds; rq.K = K; rq.S = S;
+    switch (a->kind) {
+    case MDT_KIND_BASIC: rq.basic = 1; rq.need_rb = 1; rq.out_rb = rhat_out; break;
+    case MDT_KIND_BULK: rq.need_rb = 1; rq.out_rb = rhat_out; break;
+    case MDT_KIND_TAIL: rq.need_rt = 1; rq.out_rt = rhat_out; break;
+    case MDT_KIND_RANK: rq.need_rb = 1; rq.need_rt = 1; rq.out_rrank = rhat_out; break; // map(max, Rbulk, Rtail), :124
+    default: return fail(ctx, MDT_EARG, "the `kind` is not supported by `rhat_nested`"); // :64
+    }
+    return run(ctx, a, x, rq);
+}
+
+int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out) {
+    if (!ctx) return MDT_EARG;
+    if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
+    Req rq;
+    rq.mode = 2; rq.basic = 1; rq.need_eb = 1; rq.out_eb = mcse_out; rq.want_ess = 1;
+    return run(ctx, a, x, rq);
+}
+
+int mdt_rank_normalize(mdt_ctx* ctx, const mdt_args* a, const void* x, int32_t fold, double* rank_out,
+                       void* z_out) {
+    if (!ctx) return MDT_EARG;
+    if (!rank_out && !z_out) return fail(ctx, MDT_EARG, "all outputs are NULL");
+    Req rq;
+    rq.mode = 3; rq.fold = fold ? 1 : 0; rq.rank_out = rank_out; rq.z_out = z_out;
+    return run(ctx, a, x, rq);
+}
+
+} // extern "C"
