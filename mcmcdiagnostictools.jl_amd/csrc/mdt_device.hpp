@@ -74,10 +74,11 @@ constexpr int OFF_AUX = OFF_PART + NWAVE * 8 * 8;         // double aux[2*NLAGTA
 constexpr int LDS_SER_END = OFF_AUX + 2 * NLAGTAB * 8;
 // indicator phase view of the big region
 constexpr int OFF_BITS = OFF_BIG;                         // uint64 bits[2][BITW]  raw ballots of one chain
-constexpr int BITW = 4096;                                // => draws <= 262144
+constexpr int BITW = 2048;                                // => draws <= 131072
 constexpr int OFF_SBITS = OFF_BITS + 2 * BITW * 8;        // uint64 sbits[2][BITW] split-aligned words
 constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
-constexpr int OFF_IVAR = OFF_ICNT + 2 * NLAGTAB * 8;      // double imean[2][MAXM], ivar via mean
+constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})
+constexpr int OFF_IVAR = OFF_IDIF + 2 * NLAGTAB * 8;      // double imean[2][MAXM]
 constexpr int LDS_IND_END = OFF_IVAR + 2 * MAXM * 8;
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int LDS_BYTES = cmax(LDS_RANK_END, cmax(LDS_SER_END, LDS_IND_END));
@@ -666,6 +667,7 @@ __device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double
     unsigned long long* sbits = (unsigned long long*)(smem + OFF_SBITS);
     double* icov = (double*)(smem + OFF_ICNT);
     double* imean = (double*)(smem + OFF_IVAR);
+    double* idif = (double*)(smem + OFF_IDIF);
     const long long niter = kp.niter, D = kp.D, maxlag = kp.maxlag;
     const int s = kp.s, m = kp.m;
     const int nwD = (int)((D + 63) >> 6);
@@ -674,7 +676,7 @@ __device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double
     const double dn = (double)niter;
 
     long long k0 = 0;
-    for (int k = tid; k < 2 * NLAGTAB; k += NT) icov[k] = 0.0;
+    for (int k = tid; k < 2 * NLAGTAB; k += NT) { icov[k] = 0.0; idif[k] = 0.0; }
     if (tid < 2) { ints[4 + tid] = 0; ints[6 + tid] = 0; } // started, done per indicator
     __syncthreads();
     while (true) {
@@ -723,6 +725,9 @@ __device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double
                         const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
                         const double ck = (double)N / (dn * dn);
                         icov[ind * NLAGTAB + k] += ck;
+                        // variogram numerator (BDA, src/ess_rhat.jl:204-212): the mean cancels in
+                        // c_t - c_{t+k}, so sum_t (I_t - I_{t+k})^2 = #(I_t != I_{t+k}) = H + T - 2A
+                        idif[ind * NLAGTAB + k] += (double)(Hk + Tk - 2 * Ak);
                         if (k == 0) imean[ind * MAXM + j] = (double)Sx / dn;
                     }
                 }
@@ -744,7 +749,12 @@ __device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double
             vb /= (double)(m > 1 ? m - 1 : m);
             const double varp = kp.cf * W + vb;
             const double inv_varp = 1.0 / varp;
-            auto rho = [&](long long k) -> double { return 1.0 - inv_varp * (W - cv[k] / dm / dn); };
+            const double* dv = idif + ind * NLAGTAB;
+            const int bda = kp.method == 2;
+            auto rho = [&](long long k) -> double {
+                const double ma = bda ? W - dv[k] / dm / (2.0 * (double)(niter - k)) : cv[k] / dm / dn;
+                return 1.0 - inv_varp * (W - ma);
+            };
             double pt = scal[8 + 4 * ind], sum = scal[9 + 4 * ind];
             long long k = (long long)scal[10 + 4 * ind];
             const long long avail = kend - 1;

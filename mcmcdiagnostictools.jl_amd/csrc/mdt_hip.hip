@@ -131,7 +131,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (m > MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
     if (maxlag > MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
-    if (rq.need_et && D > (long long)BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 262144 not supported for tail ESS");
+    if (rq.need_et && D > (long long)BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
     if (a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok)
         return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod is not implemented on the device yet");
 

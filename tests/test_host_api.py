@@ -1,0 +1,89 @@
+"""CPU: host-side logic of the API mirror that runs before anything touches the GPU --
+argument validation with the reference's error behaviour, superchain bookkeeping, sharding."""
+import numpy as np
+import pytest
+
+import __graft_entry__ as g
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return g.load_package()
+
+
+def test_unknown_kind_raises_argument_error(pkg):
+    # test/ess_rhat.jl:94-97
+    x = np.zeros((5, 3, 5))
+    for f in (pkg.ess, pkg.ess_rhat, pkg.rhat):
+        with pytest.raises(pkg.ArgumentError):
+            f(x, kind="foo")
+    with pytest.raises(pkg.ArgumentError):
+        pkg.ess(x, kind=lambda v: v.mean())  # mymean: unsupported estimator
+    with pytest.raises(pkg.ArgumentError):
+        pkg.ess(x, kind="rank")  # `ess` has no :rank kind (src/ess_rhat.jl:279-286)
+
+
+def test_autocov_method_types(pkg):
+    assert issubclass(pkg.AutocovMethod, pkg.AbstractAutocovMethod)
+    assert issubclass(pkg.FFTAutocovMethod, pkg.AbstractAutocovMethod)
+    assert issubclass(pkg.BDAAutocovMethod, pkg.AbstractAutocovMethod)
+
+    class Mine(pkg.AbstractAutocovMethod):
+        pass
+    with pytest.raises(pkg.ArgumentError):
+        pkg.ess(np.zeros((100, 2, 1)), autocov_method=Mine())
+
+
+def test_validate_superchain_ids(pkg):
+    # src/rhat_nested.jl:68-81, test/rhat_nested.jl:39-60
+    from mcmcdiagnostictools_jl_amd.api import _validate_superchain_ids as v
+    inds = v([2, 1, 1, 2, 3, 3], 6)
+    assert inds.shape == (2, 3) and inds.flags.f_contiguous
+    assert inds.T.tolist() == [[1, 2], [0, 3], [4, 5]]  # sorted unique ids, ascending chain indices
+    assert v(["b", "a", "b", "a"], 4).T.tolist() == [[1, 3], [0, 2]]
+    with pytest.raises(pkg.DimensionMismatch):
+        v([1, 2, 3], 4)
+    with pytest.raises(pkg.ArgumentError):
+        v([1, 1, 1, 1], 4)  # < 2 superchains
+    with pytest.raises(pkg.ArgumentError):
+        v([1, 1, 1, 2], 4)  # unequal sizes
+    with pytest.raises(pkg.ArgumentError):
+        pkg.rhat_nested(np.zeros(10), [1] * 10)  # needs >= 2 dims
+    with pytest.raises(pkg.ArgumentError):
+        pkg.rhat_nested(np.zeros((10, 4, 2)), [1, 1, 2, 2], kind="foo")
+
+
+def test_keyword_types(pkg):
+    with pytest.raises(TypeError):
+        pkg.ess(np.zeros((100, 2, 1)), maxlag=2.5)
+    with pytest.raises(TypeError):
+        pkg.rhat(np.zeros((100, 2, 1)), split_chains=2.0)
+
+
+def test_prepare_layout_and_shapes(pkg):
+    from mcmcdiagnostictools_jl_amd.api import _prepare
+    import torch
+    x = np.arange(2 * 3 * 4 * 5, dtype=np.float64).reshape(2, 3, 4, 5)
+    pr = _prepare(x)
+    assert (pr.D, pr.C, pr.P) == (2, 3, 20) and pr.param_shape == (4, 5) and not pr.scalar
+    # memory is (params, chains, draws): draws fastest, param (i, j) -> flat i*5 + j
+    assert pr.buf.shape == (20, 3, 2)
+    assert np.array_equal(pr.buf[7], x[:, :, 1, 2].T)
+    assert _prepare(np.zeros(7)).scalar and _prepare(np.zeros((7, 2))).scalar
+    assert _prepare(np.zeros(7, dtype=np.int64)).buf.dtype == np.float64  # Int -> Float64
+    assert _prepare(np.zeros((7, 2, 1), dtype=np.float32)).f32
+    t = torch.zeros(5, 4, 100).permute(2, 1, 0)  # already draws-fastest: no copy
+    pr = _prepare(t)
+    assert pr.buf.data_ptr() == t.data_ptr()
+    xm = np.ma.MaskedArray(np.zeros((10, 2, 3)), mask=False)
+    xm[0, 0, 1] = np.ma.masked
+    assert _prepare(xm).missing.tolist() == [False, True, False]
+
+
+def test_shard_bounds(pkg):
+    for P, W in ((10, 2), (10, 3), (7, 8), (1_000_000, 8)):
+        b = [pkg.shard_bounds(P, r, W) for r in range(W)]
+        assert b[0][0] == 0 and b[-1][1] == P
+        assert all(b[i][1] == b[i + 1][0] for i in range(W - 1))
+        sizes = [hi - lo for lo, hi in b]
+        assert max(sizes) - min(sizes) <= 1
