@@ -126,6 +126,13 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_
 int mdt_rank_normalize(mdt_ctx* ctx, const mdt_args* args, const void* x, int32_t fold,
                        double* rank_out, void* z_out);
 
+/*
+ * Diagnostics (no reference counterpart): per-phase shader-clock totals summed over workgroups,
+ * 16 slots (see the PH_* enum in csrc/mdt_device.hpp).  Only available when the context was
+ * created with MDT_PROF=1 in the environment; the counters cost one branch per phase otherwise.
+ */
+int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset);
+
 #ifdef __cplusplus
 }
 #endif

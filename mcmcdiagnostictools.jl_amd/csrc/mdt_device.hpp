@@ -39,7 +39,8 @@ constexpr int BIN_TOPEQ = NREG + 1; // equal to the largest sample value (reserv
 constexpr int BIN_OVER = NREG + 2;  // above the largest sample value
 constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless / stable sortperm)
 constexpr int NBIN = NREG + 4;
-constexpr int CH = 13824;           // elements of bin-ordered data staged in LDS per round
+constexpr int CH = 13760;           // elements of bin-ordered data staged in LDS per round
+constexpr int GRID = 2048;          // uniform cells over [min sample, max sample] that seed the splitter search
 constexpr int MAXROUNDS = 320;      // => n <= ~4.4M elements per parameter
 constexpr int TL = 8192;            // series tile (elements of one split chain resident in LDS)
 constexpr int HALO = 1040;          // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
@@ -51,7 +52,8 @@ constexpr int NLAGTAB = 1024;
 constexpr int OFF_RED = 0;                                // double red[32]
 constexpr int OFF_OSTAT = OFF_RED + 32 * 8;               // double ostat[8]
 constexpr int OFF_SCAL = OFF_OSTAT + 8 * 8;               // double scal[24]
-constexpr int OFF_TPOS = OFF_SCAL + 24 * 8;               // uint32 tpos[8]
+constexpr int OFF_PROFT = OFF_SCAL + 24 * 8;              // int64 last profiling stamp
+constexpr int OFF_TPOS = OFF_PROFT + 8;                   // uint32 tpos[8]
 constexpr int OFF_INTS = OFF_TPOS + 8 * 4;                // int ints[24]
 constexpr int OFF_WTOT = OFF_INTS + 24 * 4;               // uint32 wtot[16]
 constexpr int OFF_RLO = OFF_WTOT + 16 * 4;                // int rlo[MAXROUNDS]
@@ -64,14 +66,15 @@ constexpr int OFF_BIG = ((OFF_VAR + MAXM * 8 + 15) / 16) * 16;
 constexpr int OFF_SPLT = OFF_BIG;                         // double t[K1+2]
 constexpr int OFF_SPLS = OFF_SPLT + (K1 + 2) * 8;         // double scale[K1]
 constexpr int OFF_CUR = OFF_SPLS + K1 * 8;                // uint32 cur[NBIN+4]
-constexpr int OFF_CHUNK = ((OFF_CUR + (NBIN + 4) * 4 + 15) / 16) * 16; // double chunk[CH]
+constexpr int OFF_LUT = OFF_CUR + (NBIN + 4) * 4;         // uint32 lut[GRID]: (klo | khi << 16) per cell
+constexpr int OFF_CHUNK = ((OFF_LUT + GRID * 4 + 15) / 16) * 16; // double chunk[CH]
 constexpr int LDS_RANK_END = OFF_CHUNK + CH * 8;
 // series phase view of the big region
-constexpr int OFF_SER = OFF_BIG;                          // double ser[TL+HALO]
-constexpr int OFF_LAGA = OFF_SER + (TL + HALO) * 8;       // double A[NLAGTAB]   sum over chains of lag sums
-constexpr int OFF_PART = OFF_LAGA + NLAGTAB * 8;          // double part[NWAVE*8]
-constexpr int OFF_AUX = OFF_PART + NWAVE * 8 * 8;         // double aux[2*NLAGTAB] (bda head/tail squares)
-constexpr int LDS_SER_END = OFF_AUX + 2 * NLAGTAB * 8;
+constexpr int OFF_LAGA = OFF_BIG;                         // double A[NLAGTAB]   sum over chains of lag sums
+constexpr int OFF_AUX = OFF_LAGA + NLAGTAB * 8;           // double aux[2*NLAGTAB] (bda head/tail squares)
+constexpr int OFF_PART = OFF_AUX + 2 * NLAGTAB * 8;       // double part[NWAVE*8]
+constexpr int OFF_SER = OFF_PART + NWAVE * 8 * 8;         // double ser[TL+HALO]
+constexpr int LDS_SER_END = OFF_SER + (TL + HALO) * 8;
 // indicator phase view of the big region
 constexpr int OFF_BITS = OFF_BIG;                         // uint64 bits[2][BITW]  raw ballots of one chain
 constexpr int BITW = 2048;                                // => draws <= 131072
@@ -104,7 +107,8 @@ struct KP {
     long long q_j[2];           // type-7 quantile: 1-based lower order statistic j (lo, hi)
     double q_g[2];              // and gamma, both evaluated in T on the host
     const double* ztab;         // normal scores by doubled rank, [2n+1]
-    unsigned int* r2buf;        // per-workgroup scratch: doubled ranks, stride n_pad
+    unsigned int* r2buf;        // per-workgroup scratch: doubled ranks, stride n_pad (streaming variant)
+    double* zbuf;               // per-workgroup scratch: normal scores (or doubled ranks) in time order, stride n_pad
     unsigned short* binbuf;     // per-workgroup scratch: bin ids, stride n_pad
     long long n_pad;
     void* out_eb; void* out_rb; void* out_et; void* out_rt; // [P] of T, or null
@@ -114,16 +118,112 @@ struct KP {
     const int* chain_inds;      // nested: K x S (device)
     int K, S;
     int* status;                // device status word (bit0: rounds overflow, bit1: NaN hit quantile)
+    unsigned long long* prof;   // optional [grid*16] phase cycle counters (diagnostics), or null
 };
+
+// phase slots of KP::prof
+enum { PH_LOAD = 0, PH_RANKX = 1, PH_SERB = 2, PH_RANKF = 3, PH_SERT = 4, PH_IND = 5, PH_OUT = 6,
+       PH_R_SAMPLE = 8, PH_R_HIST = 9, PH_R_SCAN = 10, PH_R_PLACE = 11, PH_R_COUNT = 12 };
+#define MDT_PROF_MARK(slot)                                                                   \
+    do {                                                                                      \
+        if (kp.prof && threadIdx.x == 0) {                                                    \
+            long long* pt_ = (long long*)(smem + OFF_PROFT);                                  \
+            const long long t_ = clock64();                                                   \
+            kp.prof[blockIdx.x * 16 + (slot)] += (unsigned long long)(t_ - *pt_);             \
+            *pt_ = t_;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------ uniform arguments
+// Arguments of a non-inlined device function arrive in VGPRs even when they are wave-uniform, and
+// the compiler then treats everything derived from them as divergent: `kp.field` became a
+// flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) inside the hot loops (a full memory round trip that
+// also drains every outstanding load).  These helpers move such values back to SGPRs; the parameter
+// block is read through the constant address space, i.e. with scalar loads.
+#define MDT_CA __attribute__((address_space(4)))
+#define MDT_GA __attribute__((address_space(1)))
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uni(bool v) { return __builtin_amdgcn_readfirstlane((int)v) != 0; }
+__device__ __forceinline__ long long uni(long long v) { return (long long)uni64((unsigned long long)v); }
+__device__ __forceinline__ double uni(double v) { return __longlong_as_double((long long)uni64((unsigned long long)__double_as_longlong(v))); }
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <class P>
+__device__ __forceinline__ P* uniptr(P* p) { return (P*)uni64((unsigned long long)p); }
+template <class P>
+__device__ __forceinline__ MDT_GA P* uniptr_g(P* p) { return (MDT_GA P*)uni64((unsigned long long)p); }
+#define MDT_UNIFORM_KP(kp_in) (*(const MDT_CA KP*)uni64((unsigned long long)&(kp_in)))
+
+// ------------------------------------------------------------------ value sources
+// Plain structs passed by value into the (deliberately not inlined) phase functions.  Pointers are
+// explicitly in the GLOBAL address space: across a call boundary a plain pointer is generic and
+// every access through it becomes a flat_load, which ties up both wait counters and serialises
+// against LDS traffic (measured: 352 flat loads + 2283 s_waitcnt in the rank phase).
+template <typename T>
+struct SrcPlain {      // x itself
+    const MDT_GA T* xp;
+    __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); }
+    __device__ __forceinline__ double operator()(long long e) const { return (double)xp[e]; }
+};
+template <typename T>
+struct SrcFold {       // |x - median|, evaluated in T like the reference (src/utils.jl:155)
+    const MDT_GA T* xp;
+    T med;
+    __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); med = uni(med); }
+    __device__ __forceinline__ double operator()(long long e) const {
+        const T d = (T)(xp[e] - med);
+        return (double)(d < (T)0 ? -d : d);
+    }
+};
+template <typename T>
+struct SerX {          // series = raw draws of chain c
+    const MDT_GA T* xp;
+    long long D;
+    __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); D = uni(D); }
+    __device__ __forceinline__ double operator()(int c, long long row) const { return (double)xp[(long long)c * D + row]; }
+};
+struct SerZ {          // series = normal scores, already in time order in the per-workgroup scratch
+    const MDT_GA double* z;
+    long long D;
+    __device__ __forceinline__ void make_uniform() { z = (const MDT_GA double*)uni64((unsigned long long)z); D = uni(D); }
+    __device__ __forceinline__ double operator()(int c, long long row) const { return z[(long long)c * D + row]; }
+};
+#define MDT_PHASE __device__ __attribute__((noinline))
+
 
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
 __device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// Wave-wide sum with DPP row shifts / row broadcasts (gfx9): ~6 VALU steps of ~10 cycles each,
+// against ~6 x 2 dependent ds_bpermute round trips (~120 cycles each) for the __shfl_xor butterfly.
+// Fixed association order -> deterministic.  The total lands in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    // bound_ctrl=true / masked rows: a lane without a source receives 0 (the `old` operand), i.e. +0.0
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_l63(double v) {
+    v = dpp_add<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add<0x118, 0xF>(v); // row_shr:8  -> lane 15 of every row holds the row sum
+    v = dpp_add<0x142, 0xA>(v); // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v); // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
     return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    v = wave_sum_l63(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -222,6 +322,34 @@ __device__ __forceinline__ int bin_of(double v, const double* __restrict__ t, co
     return 2 + lo * FINE + (int)f;
 }
 
+// Splitter search seeded by a uniform grid: cell(v) is monotone in v, and lut[cell] brackets the
+// coarse index (see build in rank_phase_reg), so the search usually needs 0-1 steps instead of 8.
+struct BinCtx {
+    double t0, top, ginv;
+};
+__device__ __forceinline__ int cell_of(double v, double t0, double ginv) {
+    double c = (v - t0) * ginv;
+    c = c < (double)(GRID - 1) ? c : (double)(GRID - 1);
+    return (int)c; // v >= t0 here, so c >= 0; NaN*0 cannot occur (ginv finite, v finite or +inf -> clamped)
+}
+__device__ __forceinline__ int bin_of_fast(double v, const BinCtx& bc, const double* __restrict__ t,
+                                           const double* __restrict__ scale, const unsigned* __restrict__ lut) {
+    if (v != v) return BIN_NAN;
+    if (v < bc.t0) return BIN_UNDER;
+    if (v >= bc.top) return (v == bc.top) ? BIN_TOPEQ : BIN_OVER;
+    const unsigned lh = lut[cell_of(v, bc.t0, bc.ginv)];
+    int lo = (int)(lh & 0xFFFFu), hi = (int)(lh >> 16); // t[lo] <= v < t[hi + 1]
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t[mid] <= v) lo = mid; else hi = mid - 1;
+    }
+    const double tk = t[lo];
+    if (v == tk) return 1 + lo * FINE;
+    double f = (v - tk) * scale[lo];
+    f = f < (double)(FINE - 2) ? f : (double)(FINE - 2);
+    return 2 + lo * FINE + (int)f;
+}
+
 __device__ __forceinline__ bool bin_reserved(int b) {
     return (b >= 1 && b <= NREG && ((b - 1) & (FINE - 1)) == 0) || b == BIN_TOPEQ;
 }
@@ -260,14 +388,40 @@ __device__ inline void wg_exscan_bins(unsigned* cur, unsigned* wtot, unsigned to
     __syncthreads();
 }
 
-// Pooled tied ranks of V(0..n) as doubled ranks r2 = 2*rank (exact integers) into r2out.
-// tpos[0..ntgt): 0-based sorted positions whose values are captured into ostat[].
-template <class VF>
-__device__ void rank_phase(VF V, long long n, unsigned char* smem, unsigned* __restrict__ r2out,
-                           unsigned short* __restrict__ binbuf, int ntgt, int* status) {
+// ------------------------------------------------------------------ rank phase, dense loops
+// Pooled tied ranks -> normal scores for a slice of any size.  No per-thread persistent state and
+// no big unrolled bodies (an earlier register-resident variant spilled into every inner loop): every
+// pass is a plain grid-stride loop over the elements with U independent loads in flight per thread.
+// All SCATTERED traffic goes through LDS; global memory only sees coalesced streams:
+//   1. histogram of bin ids (x streamed once from HBM)
+//   2. prefix -> bin starts; rounds = maximal runs of bins whose members fit the LDS chunk
+//   3. per round
+//        place   x re-streamed (Infinity Cache); elements whose value falls in the round's coarse
+//                value range get their bin, draw their sorted-order slot with one LDS atomic, drop
+//                their value at chunk[slot] and remember the slot in posbuf[e] (coalesced)
+//        count   DENSE, in slot order: thread i ranks chunk[i] inside its bin by all-pairs compares;
+//                the normal score is looked up here, where consecutive lanes hold consecutive
+//                ranks (coalesced table read), and written back over the value
+//        pickup  posbuf[e] streamed; owners of this round fetch chunk[slot] and store it in time
+//                order (coalesced)
+constexpr int DENSE_IT = (CH + NT - 1) / NT; // slot-order iterations per thread per round
+constexpr int UB = 20;                       // independent loads in flight per thread in the streaming passes
+
+template <typename PT, class VG>
+MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, PT* posbuf_,
+                            unsigned short* binbuf_, int ntgt_, int store_r2_) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    vg.make_uniform();
+    const long long n = uni(n_);
+    const int ntgt = uni(ntgt_), store_r2 = uni(store_r2_);
+    MDT_GA double* zout = uniptr_g(zout_);
+    MDT_GA PT* posbuf = uniptr_g(posbuf_);
+    MDT_GA unsigned short* binbuf = uniptr_g(binbuf_);
+    const long long step = (long long)NT * UB;
     const int tid = threadIdx.x;
-    double* red = (double*)(smem + OFF_RED);
+    const MDT_GA double* ztab = (const MDT_GA double*)kp.ztab;
     double* ostat = (double*)(smem + OFF_OSTAT);
+    double* scal = (double*)(smem + OFF_SCAL);
     unsigned* tpos = (unsigned*)(smem + OFF_TPOS);
     int* ints = (int*)(smem + OFF_INTS);
     unsigned* wtot = (unsigned*)(smem + OFF_WTOT);
@@ -277,44 +431,81 @@ __device__ void rank_phase(VF V, long long n, unsigned char* smem, unsigned* __r
     double* spl_t = (double*)(smem + OFF_SPLT);
     double* spl_s = (double*)(smem + OFF_SPLS);
     unsigned* cur = (unsigned*)(smem + OFF_CUR);
+    unsigned* lut = (unsigned*)(smem + OFF_LUT);
     double* chunk = (double*)(smem + OFF_CHUNK);
-    (void)red;
 
-    // ---- sample -> sorted -> splitters
+    // ---- sample -> sorted -> splitters -> grid LUT
     {
         const long long items = (n + NT - 1) / NT;
-        const long long j = tid % items;
-        long long e = j * NT + tid;
-        if (e >= n) e = (j > 0) ? (j - 1) * NT + tid : (long long)(tid % n);
-        double v = V(e);
+        long long js = tid % items;
+        if (js * NT + tid >= n && js > 0) --js;
+        long long es = js * NT + tid;
+        if (es >= n) es = (long long)(tid % n);
+        double v = vg(es);
         if (v != v) v = __builtin_inf();
         v = wg_bitonic_sort(v, chunk);
         if ((tid & 3) == 0) spl_t[tid >> 2] = v;
         if (tid == NT - 1) spl_t[K1] = v;
         for (int b = tid; b < NBIN + 1; b += NT) cur[b] = 0u;
         __syncthreads();
+        const double t0 = spl_t[0], top = spl_t[K1];
+        double ginv = (double)GRID / (top - t0);
+        if (!(ginv > 0.0) || !(ginv < __builtin_inf())) ginv = 0.0; // degenerate range: one cell, full search
         if (tid < K1) {
             const double w = spl_t[tid + 1] - spl_t[tid];
             double sc = (w > 0.0 && w < __builtin_inf()) ? (double)(FINE - 1) / w : 0.0;
             if (!(sc < __builtin_inf())) sc = 0.0;
             spl_s[tid] = sc;
         }
+        // hi[c] = max{k < K1 : cell(t_k) <= c}; the coarse index of any v in cell c lies in [hi[c-1], hi[c]]
+        for (int c = tid; c < GRID; c += NT) {
+            int h[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cc = c - 1 + q;
+                int lo = 0, hi = K1 - 1;
+                if (cc < 0) hi = 0;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const double tm = spl_t[mid];
+                    const bool ok = (tm < top) ? (cell_of(tm, t0, ginv) <= cc) : false;
+                    if (ok) lo = mid; else hi = mid - 1;
+                }
+                h[q] = lo;
+            }
+            lut[c] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        }
+        if (tid == 0) { scal[21] = t0; scal[22] = top; scal[23] = ginv; }
         __syncthreads();
     }
-    // ---- histogram
-    for (long long e = tid; e < n; e += NT) {
-        const int b = bin_of(V(e), spl_t, spl_s);
-        binbuf[e] = (unsigned short)b;
-        atomicAdd(&cur[b], 1u);
+    BinCtx bc;
+    bc.t0 = scal[21]; bc.top = scal[22]; bc.ginv = scal[23];
+    MDT_PROF_MARK(PH_R_SAMPLE);
+
+    // ---- 1. histogram.  Staged per batch: UB loads -> UB bin searches -> UB atomics -> UB stores, so that
+    //      each kind of latency is paid once per batch, not once per element (a per-element
+    //      `if { atomic; wait; write; store }` body serialises on lgkmcnt(0) / vmcnt).
+    for (long long e0 = tid; e0 < n; e0 += step) {
+        double xb[UB];
+        int bq[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; xb[u] = (e < n) ? vg(e) : __builtin_nan(""); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) bq[u] = bin_of_fast(xb[u], bc, spl_t, spl_s, lut); // padding -> BIN_NAN
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cur[bq[u]], 1u); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; if (e < n) binbuf[e] = (unsigned short)bq[u]; }
     }
     __syncthreads();
+    MDT_PROF_MARK(PH_R_HIST);
+    // ---- 2. starts and rounds
     wg_exscan_bins(cur, wtot, (unsigned)n);
-    // ---- rounds: maximal runs of consecutive bins that fit the LDS chunk
     if (tid == 0) {
         int nr = 0, b = 0;
-        const unsigned nn = cur[BIN_NAN]; // number of non-NaN elements
+        const unsigned nn = cur[BIN_NAN];
         while (b < BIN_NAN && cur[b] < nn) {
-            if (nr >= MAXROUNDS) { atomicOr(status, 1); break; }
+            if (nr >= MAXROUNDS) { atomicOr(kp.status, 1); break; }
             const unsigned base = cur[b];
             int lo = b, hi = BIN_NAN;
             while (lo < hi) {
@@ -323,94 +514,161 @@ __device__ void rank_phase(VF V, long long n, unsigned char* smem, unsigned* __r
             }
             rbase[nr] = base;
             rlo[nr] = b;
-            if (lo == b) { rhi[nr] = -1; b = b + 1; }  // a single bin larger than the chunk
+            if (lo == b) { rhi[nr] = -(b + 1) - 1; b = b + 1; } // a single bin larger than the chunk: -(hi) - 1
             else { rhi[nr] = lo; b = lo; }
             ++nr;
         }
         ints[0] = nr;
+        ints[10] = (int)nn;
     }
     __syncthreads();
+    MDT_PROF_MARK(PH_R_SCAN);
     const int nr = ints[0];
     for (int r = 0; r < nr; ++r) {
-        const int lo = rlo[r], hi = rhi[r];
+        const int lo = rlo[r];
+        const bool oversize = rhi[r] < 0;
+        const int hi = oversize ? lo + 1 : rhi[r];
         const unsigned base = rbase[r];
-        if (hi >= 0) {
-            // place the members of bins [lo, hi) into the chunk, bin by bin
-            for (long long e = tid; e < n; e += NT) {
-                const int b = binbuf[e];
-                if (b >= lo && b < hi) {
-                    const unsigned pos = atomicAdd(&cur[b], 1u);
-                    chunk[pos - base] = V(e);
+        const unsigned cnt = cur[hi] - base; // cur[hi] is still the START of bin hi
+        // value range of the coarse buckets that overlap bins [lo, hi): a cheap superset filter
+        const double vlo = (lo == 0) ? -__builtin_inf() : spl_t[(lo - 1) / FINE < K1 ? (lo - 1) / FINE : K1];
+        const bool top_open = (hi - 1) > NREG;
+        const double vhi = top_open ? __builtin_inf() : spl_t[(hi - 2) / FINE + 1];
+        __syncthreads(); // everyone has read cur[hi] before the atomics below move it
+        if (!oversize) {
+            // 3a. place: bin ids (2 B) and values (8 B) streamed together, both unconditionally; staged
+            for (long long e0 = tid; e0 < n; e0 += step) {
+                double xb[UB];
+                int bq[UB];
+                unsigned ps[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const long long e = e0 + (long long)u * NT;
+                    bq[u] = (e < n) ? (int)binbuf[e] : 0xFFFF;
+                    xb[u] = (e < n) ? vg(e) : 0.0;
                 }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { ps[u] = 0u; if (bq[u] >= lo && bq[u] < hi) ps[u] = atomicAdd(&cur[bq[u]], 1u); }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { if (bq[u] >= lo && bq[u] < hi) chunk[ps[u] - base] = xb[u]; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { if (bq[u] >= lo && bq[u] < hi) posbuf[e0 + (long long)u * NT] = (PT)ps[u]; }
             }
-            __syncthreads();
-            // count: rank inside the bin by all-pairs comparison
-            for (long long e = tid; e < n; e += NT) {
-                const int b = binbuf[e];
-                if (b >= lo && b < hi) {
+            __syncthreads(); // cur[b] is now the END of every bin of this round; the start is cur[b-1]
+            MDT_PROF_MARK(PH_R_PLACE);
+            // 3b. dense count in slot order
+            unsigned res[DENSE_IT];
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                res[k] = 2u;
+                if (i < cnt) {
+                    const double v = chunk[i];
+                    const int b = bin_of_fast(v, bc, spl_t, spl_s, lut);
                     const unsigned st = (b > 0) ? cur[b - 1] : 0u;
                     const unsigned en = cur[b];
-                    const double v = V(e);
                     unsigned less = st, eq;
                     if (bin_reserved(b)) {
                         eq = en - st;
                     } else {
                         eq = 0;
-                        for (unsigned i = st; i < en; ++i) {
-                            const double y = chunk[i - base];
-                            less += (y < v) ? 1u : 0u;
-                            eq += (y == v) ? 1u : 0u;
+                        const unsigned last = en - 1u - base;
+                        for (unsigned m2 = st - base; m2 <= last; m2 += 4u) {
+                            // 4 independent LDS reads per trip; indices past the bin are clamped to its
+                            // last member and masked out of the counts
+                            const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
+                            const double y0 = chunk[m2];
+                            const double y1 = chunk[i1 <= last ? i1 : last];
+                            const double y2 = chunk[i2 <= last ? i2 : last];
+                            const double y3 = chunk[i3 <= last ? i3 : last];
+                            less += (y0 < v) ? 1u : 0u;
+                            eq += (y0 == v) ? 1u : 0u;
+                            less += (i1 <= last && y1 < v) ? 1u : 0u;
+                            eq += (i1 <= last && y1 == v) ? 1u : 0u;
+                            less += (i2 <= last && y2 < v) ? 1u : 0u;
+                            eq += (i2 <= last && y2 == v) ? 1u : 0u;
+                            less += (i3 <= last && y3 < v) ? 1u : 0u;
+                            eq += (i3 <= last && y3 == v) ? 1u : 0u;
                         }
                     }
-                    r2out[e] = 2u * less + eq + 1u;
-                    for (int i = 0; i < ntgt; ++i)
-                        if (tpos[i] - less < eq) ostat[i] = v;
+                    res[k] = 2u * less + eq + 1u;
+                    for (int t = 0; t < ntgt; ++t)
+                        if (tpos[t] - less < eq) ostat[t] = v;
                 }
             }
+            // normal scores by doubled rank: consecutive lanes read consecutive table entries
+            double zz[DENSE_IT];
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ztab[res[k]];
             __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                if (i < cnt) chunk[i] = zz[k];
+            }
+            __syncthreads();
+            MDT_PROF_MARK(PH_R_COUNT);
+            // 3c. pickup, staged
+            for (long long e0 = tid; e0 < n; e0 += step) {
+                PT pb[UB];
+                int bq[UB];
+                double zq[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const long long e = e0 + (long long)u * NT;
+                    bq[u] = (e < n) ? (int)binbuf[e] : 0xFFFF;
+                    pb[u] = (e < n) ? posbuf[e] : (PT)0;
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { zq[u] = 0.0; if (bq[u] >= lo && bq[u] < hi) zq[u] = chunk[(unsigned)pb[u] - base]; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { if (bq[u] >= lo && bq[u] < hi) zout[e0 + (long long)u * NT] = zq[u]; }
+            }
+            __syncthreads();
+            MDT_PROF_MARK(PH_R_PLACE);
         } else {
-            // oversize bin: all-equal by construction if reserved, brute force otherwise
+            // a single bin larger than the chunk: all-equal by construction if reserved, else brute force
             const int b = lo;
-            const unsigned st = base;
-            const unsigned sz = cur[b + 1] - st;
-            const bool res = bin_reserved(b);
+            const bool resv = bin_reserved(b);
             for (long long e = tid; e < n; e += NT) {
-                if (binbuf[e] == b) {
-                    const double v = V(e);
-                    unsigned less = st, eq = sz;
-                    if (!res) {
+                const double v = vg(e);
+                if (v >= vlo && (top_open || v < vhi) && bin_of_fast(v, bc, spl_t, spl_s, lut) == b) {
+                    unsigned less = base, eq = cnt;
+                    if (!resv) {
                         eq = 0;
                         for (long long i = 0; i < n; ++i) {
-                            if (binbuf[i] != b) continue;
-                            const double y = V(i);
+                            const double y = vg(i);
+                            if (bin_of_fast(y, bc, spl_t, spl_s, lut) != b) continue;
                             less += (y < v) ? 1u : 0u;
                             eq += (y == v) ? 1u : 0u;
                         }
                     }
-                    r2out[e] = 2u * less + eq + 1u;
-                    for (int i = 0; i < ntgt; ++i)
-                        if (tpos[i] - less < eq) ostat[i] = v;
+                    const unsigned r2 = 2u * less + eq + 1u;
+                    zout[e] = store_r2 ? (double)r2 : ztab[r2];
+                    for (int t = 0; t < ntgt; ++t)
+                        if (tpos[t] - less < eq) ostat[t] = v;
                 }
             }
             __syncthreads();
-            if (tid == 0) cur[b] = st + sz;
+            if (tid == 0) cur[b] = base + cnt; // keep the invariant "bins below the current round hold their END"
             __syncthreads();
         }
     }
-    // ---- NaNs rank last, in index order, never tied
-    const unsigned nn = cur[BIN_NAN];
-    if (nn < (unsigned)n) {
+    const unsigned nn = (unsigned)ints[10];
+    if (nn < (unsigned)n) { // NaNs rank last, in index order, never tied
         for (long long e = tid; e < n; e += NT) {
-            if (binbuf[e] == BIN_NAN) {
+            const double v = vg(e);
+            if (v != v) {
                 unsigned less = nn;
-                for (long long i = 0; i < e; ++i) less += (binbuf[i] == BIN_NAN) ? 1u : 0u;
-                r2out[e] = 2u * less + 2u;
-                for (int i = 0; i < ntgt; ++i)
-                    if (tpos[i] == less) ostat[i] = __builtin_nan("");
+                for (long long i = 0; i < e; ++i) { const double y = vg(i); less += (y != y) ? 1u : 0u; }
+                const unsigned r2 = 2u * less + 2u;
+                zout[e] = store_r2 ? (double)r2 : ztab[r2];
+                for (int t = 0; t < ntgt; ++t)
+                    if (tpos[t] == less) ostat[t] = __builtin_nan("");
             }
         }
     }
-    if (tid == 0) ints[9] = (nn < (unsigned)n) ? 1 : 0; // any NaN in this slice
+    if (tid == 0) ints[9] = (nn < (unsigned)n) ? 1 : 0;
     __syncthreads();
 }
 
@@ -448,10 +706,87 @@ struct Geyer {
     int started, done;
 };
 
+
+// Combine on one lane: W, var+, R-hat from mean_j / var_j (src/ess_rhat.jl:537-545) after the first
+// lag block, then Geyer's initial monotone sequence (:555-594) over the lags available so far.
+// State between blocks lives in scal[4..6], ints[1] (started), ints[2] (done).
+template <class KPT>
+__device__ inline void series_combine(const KPT& kp, unsigned char* smem, int block, long long kend, bool want_acov) {
+    double* scal = (double*)(smem + OFF_SCAL);
+    int* ints = (int*)(smem + OFF_INTS);
+    double* mean_j = (double*)(smem + OFF_MEAN);
+    double* var_j = (double*)(smem + OFF_VAR);
+    double* A = (double*)(smem + OFF_LAGA);
+    double* aux = (double*)(smem + OFF_AUX);
+    const long long niter = kp.niter, maxlag = kp.maxlag;
+    const int m = kp.m, method = kp.method;
+    if (block == 0) {
+        double W = 0.0, mb = 0.0;
+        for (int j = 0; j < m; ++j) { W += var_j[j]; mb += mean_j[j]; }
+        W /= (double)m;
+        mb /= (double)m;
+        double vb = 0.0;
+        for (int j = 0; j < m; ++j) { const double d = mean_j[j] - mb; vb = fma(d, d, vb); }
+        vb /= (double)(m > 1 ? m - 1 : m);
+        const double varp = kp.cf * W + vb;
+        scal[0] = W;
+        scal[1] = varp;
+        scal[2] = sqrt(varp / W);
+    }
+    if (!want_acov) { ints[2] = 1; return; }
+    const double W = scal[0], inv_varp = 1.0 / scal[1];
+    const double dm = (double)m, dn = (double)niter;
+    auto rho = [&](long long k) -> double {
+        double ma;
+        if (method == 2) {
+            const double n2 = (double)(niter - k);
+            const double sdiff = (2.0 * A[0] - aux[k] - aux[NLAGTAB + k] - 2.0 * A[k]) / dm;
+            ma = W - sdiff / (2.0 * n2);
+        } else {
+            ma = A[k] / dm / dn;
+        }
+        return 1.0 - inv_varp * (W - ma);
+    };
+    double pt = scal[4], sum = scal[5];
+    long long k = (long long)scal[6];
+    int done = 0;
+    const long long avail = kend - 1; // largest lag available
+    if (!ints[1]) {
+        const double rho_odd = rho(1);
+        pt = 1.0 + rho_odd;
+        sum = pt;
+        k = 2;
+        ints[1] = 1;
+    }
+    int stop = 0; // loop finished (break or bound)
+    while (k < maxlag - 1) {
+        if (k + 1 > avail) break;
+        const double delta = rho(k) + rho(k + 1);
+        if (!(delta > 0.0)) { stop = 1; break; }
+        pt = jl_min(delta, pt);
+        sum += pt;
+        k += 2;
+    }
+    if (!(k < maxlag - 1)) stop = 1;
+    if (stop && (k <= avail || !(maxlag > 1))) {
+        const double rho_even = (maxlag > 1) ? rho(k) : 0.0;
+        const double tau = jl_max(0.0, 2.0 * sum + jl_max(0.0, rho_even) - 1.0);
+        double e = jl_min(1.0 / tau, kp.rel_ess_max);
+        if (!kp.relative) e *= kp.ntotal;
+        scal[3] = e;
+        done = 1;
+    }
+    scal[4] = pt; scal[5] = sum; scal[6] = (double)k;
+    ints[2] = done;
+}
+
 // Y(c, row) -> value of the series for original chain c at draw `row`.
 // Leaves mean_j / var_j of every split chain in LDS; returns rhat (and ess if want_acov).
 template <class YF>
-__device__ SeriesOut series_phase(const KP& kp, YF Y, bool want_acov, unsigned char* smem) {
+MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned char* smem) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    Y.make_uniform();
+    const bool want_acov = uni(want_acov_);
     const int tid = threadIdx.x;
     double* red = (double*)(smem + OFF_RED);
     double* scal = (double*)(smem + OFF_SCAL);
@@ -499,10 +834,21 @@ __device__ SeriesOut series_phase(const KP& kp, YF Y, bool want_acov, unsigned c
                     const long long tau = (long long)ti * TL;
                     const int tlen = (int)((niter - tau < TL) ? niter - tau : TL);
                     double loc = 0.0;
-                    for (int i = tid; i < tlen; i += NT) {
-                        const double v = Y(c, r0 + tau + i);
-                        if (ntile == 1) ser[i] = v;
-                        loc += v;
+                    for (int i0 = tid; i0 < tlen; i0 += NT * 8) { // 8 loads in flight per thread
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * NT;
+                            v[u] = (i < tlen) ? Y(c, r0 + tau + i) : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * NT;
+                            if (i < tlen) {
+                                if (ntile == 1) ser[i] = v[u];
+                                loc += v[u];
+                            }
+                        }
                     }
                     sum += wg_sum(loc, red);
                 }
@@ -521,9 +867,18 @@ __device__ SeriesOut series_phase(const KP& kp, YF Y, bool want_acov, unsigned c
                     for (int i = tid; i < tlen + halo; i += NT) ser[i] = (i < tlen) ? ser[i] - mu : 0.0;
                 } else {
                     __syncthreads();
-                    for (int i = tid; i < tlen + halo; i += NT) {
-                        const long long t = tau + i;
-                        ser[i] = (t < niter) ? Y(c, r0 + t) - mu : 0.0;
+                    for (int i0 = tid; i0 < tlen + halo; i0 += NT * 8) {
+                        double v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * NT;
+                            v[u] = (i < tlen + halo && tau + i < niter) ? Y(c, r0 + tau + i) - mu : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const int i = i0 + u * NT;
+                            if (i < tlen + halo) ser[i] = v[u];
+                        }
                     }
                 }
                 __syncthreads();
@@ -570,70 +925,7 @@ __device__ SeriesOut series_phase(const KP& kp, YF Y, bool want_acov, unsigned c
                 __syncthreads();
             }
         }
-        // ---- combine on one lane (src/ess_rhat.jl:537-594)
-        if (tid == 0) {
-            if (block == 0) {
-                double W = 0.0, mb = 0.0;
-                for (int j = 0; j < m; ++j) { W += var_j[j]; mb += mean_j[j]; }
-                W /= (double)m;
-                mb /= (double)m;
-                double vb = 0.0;
-                for (int j = 0; j < m; ++j) { const double d = mean_j[j] - mb; vb = fma(d, d, vb); }
-                vb /= (double)(m > 1 ? m - 1 : m);
-                const double varp = kp.cf * W + vb;
-                scal[0] = W;
-                scal[1] = varp;
-                scal[2] = sqrt(varp / W);
-            }
-            if (want_acov) {
-                const double W = scal[0], inv_varp = 1.0 / scal[1];
-                const double dm = (double)m, dn = (double)niter;
-                auto rho = [&](long long k) -> double {
-                    double ma;
-                    if (method == 2) {
-                        const double n2 = (double)(niter - k);
-                        const double sdiff = (2.0 * A[0] - aux[k] - aux[NLAGTAB + k] - 2.0 * A[k]) / dm;
-                        ma = W - sdiff / (2.0 * n2);
-                    } else {
-                        ma = A[k] / dm / dn;
-                    }
-                    return 1.0 - inv_varp * (W - ma);
-                };
-                double pt = scal[4], sum = scal[5];
-                long long k = (long long)scal[6];
-                int done = 0;
-                const long long avail = kend - 1; // largest lag available
-                if (!ints[1]) {
-                    const double rho_odd = rho(1);
-                    pt = 1.0 + rho_odd;
-                    sum = pt;
-                    k = 2;
-                    ints[1] = 1;
-                }
-                int stop = 0; // loop finished (break or bound)
-                while (k < maxlag - 1) {
-                    if (k + 1 > avail) break;
-                    const double delta = rho(k) + rho(k + 1);
-                    if (!(delta > 0.0)) { stop = 1; break; }
-                    pt = jl_min(delta, pt);
-                    sum += pt;
-                    k += 2;
-                }
-                if (!(k < maxlag - 1)) stop = 1;
-                if (stop && (k <= avail || !(maxlag > 1))) {
-                    const double rho_even = (maxlag > 1) ? rho(k) : 0.0;
-                    const double tau = jl_max(0.0, 2.0 * sum + jl_max(0.0, rho_even) - 1.0);
-                    double e = jl_min(1.0 / tau, kp.rel_ess_max);
-                    if (!kp.relative) e *= kp.ntotal;
-                    scal[3] = e;
-                    done = 1;
-                }
-                scal[4] = pt; scal[5] = sum; scal[6] = (double)k;
-                ints[2] = done;
-            } else {
-                ints[2] = 1;
-            }
-        }
+        if (tid == 0) series_combine(kp, smem, block, kend, want_acov);
         __syncthreads();
         if (ints[2]) break;
         k0 = kend;
@@ -641,6 +933,229 @@ __device__ SeriesOut series_phase(const KP& kp, YF Y, bool want_acov, unsigned c
     }
     out.rhat = scal[2];
     if (want_acov) out.ess = scal[3];
+    __syncthreads();
+    return out;
+}
+
+
+// ------------------------------------------------------------------ series phase for normal scores
+// The hot variant of series_phase for the rank-normalised series (values bounded, |z| < 9).
+// Moments: every thread sums u = z - K_j and u^2 over the values it loads (K_j = mean of 8 draws
+// spread over the chain: exactly 0 deviation for a constant chain), reduced per wave with DPP and
+// across waves in a fixed order.  This is the ONLY place means and variances come from, so
+// rhat(x) and ess_rhat(x).rhat are bit-identical, as in the reference (test/ess_rhat.jl:167-204).
+//   moments only (R-hat): no LDS staging, no per-chain barrier at all;
+//   with autocovariance: one split chain per LDS buffer, double buffered -> ONE barrier per split
+//   chain, the loads of chain j+1 in flight while chain j is processed; lagged products of the
+//   shifted values are centred algebraically:
+//     sum_t (u_t - mu)(u_{t+k} - mu) = P_k - mu (S1 - tail_k + S1 - head_k) + (n - k) mu^2,
+//   head_k / tail_k = sums of the first / last k values.  With |mu| << sd this loses nothing
+//   ("one-pass centring"); the reference's two-pass order (src/ess_rhat.jl:529-548) is
+//   kept for raw draws in series_phase, where offsets can be large.
+constexpr int SZ = 6400;                  // doubles per buffer: niter + lag halo must fit
+constexpr int SZ_EDGE = 256;              // first / last values kept for head_k / tail_k (maxlag <= 255)
+constexpr int ZPW = NWAVE * 8 + 2 * NWAVE; // per-chain partials: 8 lags x segments, then S1 and S2 per wave
+constexpr int ZMB = 32;                   // chains per batch in the moments-only path
+constexpr int OFF_ZSER = OFF_SER;                              // double zser[2][SZ] (A / aux shared with series_phase)
+constexpr int OFF_ZPART = OFF_ZSER + 2 * SZ * 8;               // double zpart[3][ZPW]
+constexpr int OFF_ZEDGE = OFF_ZPART + 3 * ZPW * 8;             // double zedge[3][2][SZ_EDGE]
+constexpr int OFF_ZK = OFF_ZEDGE + 3 * 2 * SZ_EDGE * 8;        // double zk[4]
+constexpr int LDS_ZSER_END = OFF_ZK + 4 * 8;
+constexpr int OFF_ZMOM = OFF_SER;                              // moments-only view: double zmom[ZMB][NWAVE][2], zkk[ZMB]
+static_assert(LDS_ZSER_END <= LDS_BYTES, "z-series view exceeds the LDS carve");
+
+MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_acov_, unsigned char* smem) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    const bool want_acov = uni(want_acov_);
+    const MDT_GA double* z = uniptr_g(z_);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* scal = (double*)(smem + OFF_SCAL);
+    int* ints = (int*)(smem + OFF_INTS);
+    double* mean_j = (double*)(smem + OFF_MEAN);
+    double* var_j = (double*)(smem + OFF_VAR);
+    double* zser = (double*)(smem + OFF_ZSER);
+    double* A = (double*)(smem + OFF_LAGA);
+    double* aux = (double*)(smem + OFF_AUX);
+    double* zpart = (double*)(smem + OFF_ZPART);
+    double* zedge = (double*)(smem + OFF_ZEDGE);
+    double* zk = (double*)(smem + OFF_ZK);
+    const long long niter = kp.niter, D = kp.D;
+    const int n = (int)niter;
+    const int m = kp.m, s = kp.s, rem = kp.rem;
+    const long long maxlag = kp.maxlag;
+    const int method = kp.method;
+    constexpr int LD = (SZ + NT - 1) / NT; // values per thread
+    const int he = n < SZ_EDGE ? n : SZ_EDGE;
+    SeriesOut out;
+
+    double v[LD];
+    double Kj = 0.0;
+    auto issue_loads = [&](int j) {
+        const int c = j / s, kk = j - c * s;
+        const MDT_GA double* zc = z + (long long)c * D + split_row0(kk, niter, rem);
+#pragma unroll
+        for (int u = 0; u < LD; ++u) {
+            const int i = u * NT + tid;
+            v[u] = (i < n) ? zc[i] : 0.0;
+        }
+        double ks = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ks += zc[((long long)u * n) >> 3];
+        Kj = ks * 0.125;
+    };
+    // this thread's share of S1 = sum u, S2 = sum u^2 (u = z - K_j), then the wave totals
+    auto wave_moments = [&](double& r1, double& r2) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int u = 0; u < LD; ++u) {
+            const int i = u * NT + tid;
+            if (i < n) { const double uu = v[u] - Kj; s1 += uu; s2 = fma(uu, uu, s2); }
+        }
+        r1 = wave_sum(s1);
+        r2 = wave_sum(s2);
+    };
+
+    if (!want_acov) {
+        // ---- moments only: registers -> DPP -> one barrier per batch of chains
+        double* zmom = (double*)(smem + OFF_ZMOM);
+        double* zkk = zmom + ZMB * NWAVE * 2;
+        for (int jb = 0; jb < m; jb += ZMB) {
+            const int nb = (m - jb < ZMB) ? m - jb : ZMB;
+            for (int jl = 0; jl < nb; ++jl) {
+                issue_loads(jb + jl);
+                double r1, r2;
+                wave_moments(r1, r2);
+                if (lane == 0) { zmom[(jl * NWAVE + w) * 2] = r1; zmom[(jl * NWAVE + w) * 2 + 1] = r2; }
+                if (tid == 0) zkk[jl] = Kj;
+            }
+            __syncthreads();
+            if (tid < nb) {
+                double S1 = 0.0, S2 = 0.0;
+                for (int q = 0; q < NWAVE; ++q) { S1 += zmom[(tid * NWAVE + q) * 2]; S2 += zmom[(tid * NWAVE + q) * 2 + 1]; }
+                const double mu = S1 / (double)n;
+                mean_j[jb + tid] = zkk[tid] + mu;
+                var_j[jb + tid] = (S2 - mu * S1) / (double)(n - 1);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) series_combine(kp, smem, 0, 1, false);
+        __syncthreads();
+        out.rhat = scal[2];
+        out.ess = __builtin_nan("");
+        __syncthreads();
+        return out;
+    }
+
+    for (int k = tid; k < NLAGTAB; k += NT) { A[k] = 0.0; aux[k] = 0.0; aux[NLAGTAB + k] = 0.0; }
+    if (tid == 0) { ints[1] = 0; ints[2] = 0; }
+    __syncthreads();
+
+    long long k0 = 0;
+    int block = 0;
+    while (true) {
+        const int G = (block == 0) ? 2 : 4;
+        long long kend = (block == 0) ? 16 : k0 + 32;
+        if (kend > maxlag + 1) kend = maxlag + 1;
+        const int nseg = NWAVE / G;
+        const int halo = (int)k0 + 8 * G;
+        const int g = w % G, q = w / G;
+        const int seglen = (n + nseg - 1) / nseg;
+        const int t0 = q * seglen;
+        const int t1 = (t0 + seglen < n) ? t0 + seglen : n;
+        const int kb = (int)k0 + 8 * g;
+
+        // finalize split chain j from the wave partials: runs on the lanes that own the lags
+        auto finalize = [&](int j) {
+            const int b3 = j % 3;
+            const double* pp = zpart + b3 * ZPW;
+            const double* eh = zedge + b3 * 2 * SZ_EDGE;
+            const double* et = eh + SZ_EDGE;
+            const long long kq = k0 + tid;
+            if (tid < 8 * G && kq < kend) {
+                double P = 0.0, S1 = 0.0, S2 = 0.0;
+                for (int q2 = 0; q2 < nseg; ++q2) P += pp[tid * nseg + q2];
+                for (int q2 = 0; q2 < NWAVE; ++q2) { S1 += pp[NWAVE * 8 + q2]; S2 += pp[NWAVE * 9 + q2]; }
+                const double mu = S1 / (double)n;
+                double head = 0.0, tail = 0.0, hsq = 0.0, tsq = 0.0;
+                const int kk2 = (int)kq < he ? (int)kq : he;
+                for (int t = 0; t < kk2; ++t) {
+                    const double a = eh[t], b = et[he - 1 - t];
+                    head += a; tail += b;
+                    hsq = fma(a, a, hsq); tsq = fma(b, b, tsq);
+                }
+                double C;
+                if (kq == 0) {
+                    C = S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
+                    var_j[j] = C / (double)(n - 1);
+                    mean_j[j] = zk[b3] + mu;
+                } else {
+                    C = P - mu * ((S1 - tail) + (S1 - head)) + (double)(n - kq) * mu * mu;
+                }
+                A[kq] += C;
+                if (method == 2) {
+                    // variogram pieces on centred values c = u - mu: sum_{t<k} c_t^2 = hsq - 2 mu head + k mu^2
+                    aux[kq] += hsq - 2.0 * mu * head + (double)kk2 * mu * mu;
+                    aux[NLAGTAB + kq] += tsq - 2.0 * mu * tail + (double)kk2 * mu * mu;
+                }
+            }
+        };
+
+        issue_loads(0);
+        for (int j = 0; j < m; ++j) {
+            double* buf = zser + (j & 1) * SZ;
+            const int b3 = j % 3;
+            double* eh = zedge + b3 * 2 * SZ_EDGE;
+            double* et = eh + SZ_EDGE;
+            double* pp = zpart + b3 * ZPW;
+#pragma unroll
+            for (int u = 0; u < LD; ++u) {
+                const int i = u * NT + tid;
+                const double uu = v[u] - Kj;
+                if (i < n) {
+                    buf[i] = uu;
+                    if (i < he) eh[i] = uu;
+                    if (i >= n - he) et[i - (n - he)] = uu;
+                } else if (i < n + halo) {
+                    buf[i] = 0.0;
+                }
+            }
+            {
+                double r1, r2;
+                wave_moments(r1, r2);
+                if (lane == 0) { pp[NWAVE * 8 + w] = r1; pp[NWAVE * 9 + w] = r2; }
+            }
+            if (tid == 0) zk[b3] = Kj;
+            MDT_PROF_MARK(13); // waiting for the loads + LDS stores + moments
+            __syncthreads();
+            MDT_PROF_MARK(14); // barrier
+            if (j + 1 < m) issue_loads(j + 1);
+            // lagged products of this wave's t-segment
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int t = t0 + lane; t < t1; t += 64) {
+                const double a = buf[t];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = fma(a, buf[t + kb + i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const double r = wave_sum(acc[i]);
+                if (lane == 0) pp[(g * 8 + i) * nseg + q] = r;
+            }
+            MDT_PROF_MARK(15); // lag products + wave reductions
+            if (j > 0) finalize(j - 1); // its partials were complete before this iteration's barrier
+            MDT_PROF_MARK(7);  // finalize
+        }
+        __syncthreads();
+        finalize(m - 1);
+        __syncthreads();
+        if (tid == 0) series_combine(kp, smem, block, kend, true);
+        __syncthreads();
+        if (ints[2]) break;
+        k0 = kend;
+        ++block;
+    }
+    out.rhat = scal[2];
+    out.ess = scal[3];
     __syncthreads();
     return out;
 }
@@ -659,7 +1174,10 @@ __device__ __forceinline__ unsigned long long bits_at(const unsigned long long* 
 // ESS of the two indicators 1[x <= q_lo], 1[x <= q_hi] (src/ess_rhat.jl:301-311): returns
 // min(ess_lo, ess_hi) with Julia's NaN-propagating min.
 template <typename T>
-__device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double qlo, double qhi, unsigned char* smem) {
+MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, double qhi_, unsigned char* smem) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    const double qlo = uni(qlo_), qhi = uni(qhi_);
+    const MDT_GA T* xp = uniptr_g(xp_);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* scal = (double*)(smem + OFF_SCAL);
     int* ints = (int*)(smem + OFF_INTS);
@@ -795,6 +1313,172 @@ __device__ double indicator_phase(const KP& kp, const T* __restrict__ xp, double
     return r;
 }
 
+// ------------------------------------------------------------------ indicator phase, register-resident
+// Pooled ballots straight from the registers (wave w, slot j holds elements j*NT + 64w .. +63, i.e.
+// word j*16 + w of the pooled bit stream), all split chains and both indicators in parallel.
+constexpr int IND_MAXW = 1536;   // words of the pooled stream per indicator (n <= 98304)
+constexpr int IND_CB = 16;       // split chains per batch (2 indicators x 16 chains = 32 units)
+constexpr int OFF_PBITS = OFF_BIG;                           // uint64 pbits[2][IND_MAXW]
+constexpr int OFF_SB2 = OFF_PBITS + 2 * IND_MAXW * 8;        // uint64 sb2[SB2_WORDS]: units packed with stride nwS
+constexpr int SB2_WORDS = 4096;
+constexpr int OFF_ITAB = OFF_SB2 + SB2_WORDS * 8;            // double itab[2][2*IND_CB][64] (cov, dif)
+constexpr int OFF_ICNT2 = OFF_ITAB + 2 * 2 * IND_CB * 64 * 8; // double icov[2][NLAGTAB], idif[2][NLAGTAB], imean[2][MAXM]
+constexpr int LDS_IND2_END = OFF_ICNT2 + (4 * NLAGTAB + 2 * MAXM) * 8;
+static_assert(LDS_IND2_END <= LDS_BYTES, "indicator (register) view exceeds the LDS carve");
+
+template <typename T>
+MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T qhi_, unsigned char* smem) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    const T qlo = uni(qlo_), qhi = uni(qhi_);
+    const MDT_GA T* xp = uniptr_g(xp_);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    double* scal = (double*)(smem + OFF_SCAL);
+    int* ints = (int*)(smem + OFF_INTS);
+    unsigned long long* pbits = (unsigned long long*)(smem + OFF_PBITS);
+    unsigned long long* sb2 = (unsigned long long*)(smem + OFF_SB2);
+    double* itab = (double*)(smem + OFF_ITAB);
+    double* icov = (double*)(smem + OFF_ICNT2);
+    double* idif = icov + 2 * NLAGTAB;
+    double* imean = idif + 2 * NLAGTAB;
+    const long long niter = kp.niter, D = kp.D, n = kp.n, maxlag = kp.maxlag;
+    const int s = kp.s, m = kp.m;
+    const int nwP = (int)((n + 63) >> 6);
+    const int nwS = (int)((niter + 63) >> 6);
+    const double dn = (double)niter;
+
+    // pooled ballots: wave w of pass j holds elements (j*NT + 64w .. +63) = word j*NWAVE + w
+    for (long long j0 = 0; j0 * NT < n; j0 += UB) {
+        T xb[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = (j0 + u) * NT + tid; xb[u] = (e < n) ? xp[e] : (T)0; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const long long e = (j0 + u) * NT + tid;
+            const unsigned long long b0 = __ballot(e < n && xb[u] <= qlo);
+            const unsigned long long b1 = __ballot(e < n && xb[u] <= qhi);
+            const long long wd = (j0 + u) * NWAVE + w;
+            if (lane == 0 && wd < IND_MAXW) { pbits[wd] = b0; pbits[IND_MAXW + wd] = b1; }
+        }
+    }
+    for (int k = tid; k < 4 * NLAGTAB; k += NT) icov[k] = 0.0;
+    if (tid < 2) { ints[4 + tid] = 0; ints[6 + tid] = 0; }
+    __syncthreads();
+
+    long long k0 = 0;
+    while (true) {
+        long long kend = k0 + 64;
+        if (kend > maxlag + 1) kend = maxlag + 1;
+        int cb = SB2_WORDS / (2 * nwS);
+        cb = cb < 1 ? 1 : (cb > IND_CB ? IND_CB : cb);
+        for (int jb = 0; jb < m; jb += cb) {
+            const int nb = (m - jb < cb) ? m - jb : cb;
+            // split-aligned words of nb chains x 2 indicators
+            for (int i = tid; i < 2 * nb * nwS; i += NT) {
+                const int u = i / nwS, wi = i - u * nwS;      // u = 2*jl + ind
+                const int jl = u >> 1, ind = u & 1;
+                const int j2 = jb + jl, c = j2 / s, kk = j2 - c * s;
+                const long long pos = (long long)c * D + split_row0(kk, niter, kp.rem) + ((long long)wi << 6);
+                unsigned long long v = bits_at(pbits + ind * IND_MAXW, pos, nwP);
+                const long long left = niter - ((long long)wi << 6);
+                if (left < 64) v &= (left <= 0) ? 0ull : ((1ull << left) - 1ull);
+                sb2[u * nwS + wi] = v;
+            }
+            __syncthreads();
+            for (int u = w; u < 2 * nb; u += NWAVE) {
+                const unsigned long long* sb = sb2 + u * nwS;
+                const long long k = k0 + lane;
+                long long Sx = 0, Ak = 0, Hk = 0, Tk = 0;
+                double ck = 0.0, dk = 0.0;
+                if (k < kend) {
+                    for (int i = 0; i < nwS; ++i) {
+                        const unsigned long long v = sb[i];
+                        const unsigned long long vs = bits_at(sb, ((long long)i << 6) + k, nwS);
+                        const long long cnt = niter - (((long long)i << 6) + k);
+                        const unsigned long long ms = cnt >= 64 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));
+                        Sx += __popcll(v);
+                        Ak += __popcll(v & vs);
+                        Tk += __popcll(vs);
+                        Hk += __popcll(v & ms);
+                    }
+                    const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
+                    ck = (double)N / (dn * dn);
+                    dk = (double)(Hk + Tk - 2 * Ak);
+                    if (k == 0) imean[(u & 1) * MAXM + jb + (u >> 1)] = (double)Sx / dn;
+                }
+                itab[u * 64 + lane] = ck;
+                itab[(2 * IND_CB + u) * 64 + lane] = dk;
+            }
+            __syncthreads();
+            // fixed-order sum over the chains of this batch
+            if (tid < 128) {
+                const int ind = tid >> 6, l = tid & 63;
+                const long long k = k0 + l;
+                if (k < kend) {
+                    double a = icov[ind * NLAGTAB + k], d = idif[ind * NLAGTAB + k];
+                    for (int jl = 0; jl < nb; ++jl) {
+                        a += itab[(2 * jl + ind) * 64 + l];
+                        d += itab[(2 * IND_CB + 2 * jl + ind) * 64 + l];
+                    }
+                    icov[ind * NLAGTAB + k] = a;
+                    idif[ind * NLAGTAB + k] = d;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid < 2) {
+            const int ind = tid;
+            const double* cv = icov + ind * NLAGTAB;
+            const double* dv = idif + ind * NLAGTAB;
+            const double dm = (double)m;
+            const double W = cv[0] / dm / (double)(niter - 1);
+            double mb = 0.0;
+            for (int j = 0; j < m; ++j) mb += imean[ind * MAXM + j];
+            mb /= dm;
+            double vb = 0.0;
+            for (int j = 0; j < m; ++j) { const double d = imean[ind * MAXM + j] - mb; vb = fma(d, d, vb); }
+            vb /= (double)(m > 1 ? m - 1 : m);
+            const double varp = kp.cf * W + vb;
+            const double inv_varp = 1.0 / varp;
+            const int bda = kp.method == 2;
+            auto rho = [&](long long k) -> double {
+                const double ma = bda ? W - dv[k] / dm / (2.0 * (double)(niter - k)) : cv[k] / dm / dn;
+                return 1.0 - inv_varp * (W - ma);
+            };
+            double pt = scal[8 + 4 * ind], sum = scal[9 + 4 * ind];
+            long long k = (long long)scal[10 + 4 * ind];
+            const long long avail = kend - 1;
+            if (!ints[6 + ind]) {
+                if (!ints[4 + ind]) { pt = 1.0 + rho(1); sum = pt; k = 2; ints[4 + ind] = 1; }
+                int stop = 0;
+                while (k < maxlag - 1) {
+                    if (k + 1 > avail) break;
+                    const double delta = rho(k) + rho(k + 1);
+                    if (!(delta > 0.0)) { stop = 1; break; }
+                    pt = jl_min(delta, pt);
+                    sum += pt;
+                    k += 2;
+                }
+                if (!(k < maxlag - 1)) stop = 1;
+                if (stop && (k <= avail || !(maxlag > 1))) {
+                    const double rho_even = (maxlag > 1) ? rho(k) : 0.0;
+                    const double tau = jl_max(0.0, 2.0 * sum + jl_max(0.0, rho_even) - 1.0);
+                    double e = jl_min(1.0 / tau, kp.rel_ess_max);
+                    if (!kp.relative) e *= kp.ntotal;
+                    scal[11 + 4 * ind] = e;
+                    ints[6 + ind] = 1;
+                }
+                scal[8 + 4 * ind] = pt; scal[9 + 4 * ind] = sum; scal[10 + 4 * ind] = (double)k;
+            }
+        }
+        __syncthreads();
+        if (ints[6] && ints[7]) break;
+        k0 = kend;
+    }
+    const double r = jl_min(scal[11], scal[15]);
+    __syncthreads();
+    return r;
+}
+
 // ------------------------------------------------------------------ the kernel
 template <typename T>
 __device__ __forceinline__ void store_out(void* p, long long i, double v) {
@@ -802,7 +1486,8 @@ __device__ __forceinline__ void store_out(void* p, long long i, double v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
+__global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
+    const KP& kp = *kpp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     double* ostat = (double*)(smem + OFF_OSTAT);
@@ -812,23 +1497,26 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
     double* mean_j = (double*)(smem + OFF_MEAN);
     double* var_j = (double*)(smem + OFF_VAR);
     const long long n = kp.n, D = kp.D;
-    unsigned* r2 = kp.r2buf + (long long)blockIdx.x * kp.n_pad;
+    double* zb = kp.zbuf + (long long)blockIdx.x * kp.n_pad;
+    unsigned* pbuf = kp.r2buf + (long long)blockIdx.x * kp.n_pad; // sorted-order slots (u16 or u32)
     unsigned short* bb = kp.binbuf + (long long)blockIdx.x * kp.n_pad;
+    const bool pos16 = n < 65535;
     const double* __restrict__ ztab = kp.ztab;
     const double nan = __builtin_nan("");
+    if (kp.prof && tid == 0) *(long long*)(smem + OFF_PROFT) = clock64();
 
     for (long long p = blockIdx.x; p < kp.P; p += gridDim.x) {
         const T* __restrict__ xp = (const T*)kp.x + p * n;
-        auto VX = [&](long long e) -> double { return (double)xp[e]; };
-        auto YX = [&](int c, long long row) -> double { return (double)xp[(long long)c * D + row]; };
-        auto YZ = [&](int c, long long row) -> double { return ztab[r2[(long long)c * D + row]]; };
+        const SrcPlain<T> VX{(const MDT_GA T*)xp};
+        const SerX<T> YX{(const MDT_GA T*)xp, D};
+        const SerZ YZ{(const MDT_GA double*)zb, D};
+        const bool zfast = (kp.niter + kp.maxlag + 40 <= SZ) && (kp.maxlag < SZ_EDGE);
 
         // nested R-hat combine from mean_j / var_j (src/rhat_nested.jl:152-184); lane 0 only
         auto nested_combine = [&]() -> double {
             const int K = kp.K, S = kp.S, s = kp.s;
             const int mk = K * s;
             double within = 0.0, smean_sum = 0.0;
-            // superchain means are kept in scal[16..] when S is small, else recomputed
             for (int k = 0; k < S; ++k) {
                 double ms = 0.0, Wk = 0.0;
                 for (int i = 0; i < K; ++i) {
@@ -892,8 +1580,10 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
                 store_out<T>(kp.out_eb, p, ess);
                 store_out<T>(kp.out_rb, p, so.rhat);
             }
+            MDT_PROF_MARK(PH_SERB);
             continue;
         }
+
 
         // ---- ranking of x; capture median / quantile neighbours on the way
         const bool need_med = kp.need_rt || (kp.mode == 3 && kp.fold);
@@ -913,7 +1603,11 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
         __syncthreads();
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
-        if (need_rank_x) rank_phase(VX, n, smem, r2, bb, ntgt, kp.status);
+        if (need_rank_x) {
+            if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
+            else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
+        }
+        MDT_PROF_MARK(PH_RANKX);
 
         // order statistics -> median / quantiles, in T arithmetic like the reference
         T medT = (T)0, qloT = (T)0, qhiT = (T)0;
@@ -940,16 +1634,18 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
             }
         }
         __syncthreads();
+        const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
+        auto rank_folded = [&]() {
+            if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
+            else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, 0, kp.mode == 3);
+        };
 
         if (kp.mode == 3) { // stage output: _rank_normalize of x or of the folded x
-            if (kp.fold) {
-                auto VF = [&](long long e) -> double { const T d = (T)(xp[e] - medT); return (double)(d < (T)0 ? -d : d); };
-                rank_phase(VF, n, smem, r2, bb, 0, kp.status);
-            }
+            if (kp.fold) rank_folded();
             for (long long e = tid; e < n; e += NT) {
-                const unsigned r = r2[e];
-                if (kp.rank_out) kp.rank_out[p * n + e] = (double)r * 0.5;
-                if (kp.z_out) ((T*)kp.z_out)[p * n + e] = (T)ztab[r];
+                const double r = zb[e]; // doubled rank (store_r2 mode)
+                if (kp.rank_out) kp.rank_out[p * n + e] = r * 0.5;
+                if (kp.z_out) ((T*)kp.z_out)[p * n + e] = (T)ztab[(unsigned)r];
             }
             __syncthreads();
             continue;
@@ -958,7 +1654,7 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
         double eb = nan, rb = nan, et = nan, rt = nan;
         if (kp.need_eb || kp.need_rb) {
             const bool acov = kp.need_eb && kp.ess_ok;
-            const SeriesOut so = series_phase(kp, YZ, acov, smem);
+            const SeriesOut so = zfast ? series_z_phase(kp, zb, acov, smem) : series_phase(kp, YZ, acov, smem);
             rb = (kp.mode == 1) ? 0.0 : so.rhat;
             if (acov) eb = so.ess;
             if (kp.mode == 1) {
@@ -968,10 +1664,11 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
                 __syncthreads();
             }
         }
+        MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
-            auto VF = [&](long long e) -> double { const T d = (T)(xp[e] - medT); return (double)(d < (T)0 ? -d : d); };
-            rank_phase(VF, n, smem, r2, bb, 0, kp.status);
-            const SeriesOut so = series_phase(kp, YZ, false, smem);
+            rank_folded();
+            MDT_PROF_MARK(PH_RANKF);
+            const SeriesOut so = zfast ? series_z_phase(kp, zb, false, smem) : series_phase(kp, YZ, false, smem);
             rt = so.rhat;
             if (kp.mode == 1) {
                 if (tid == 0) scal[20] = nested_combine();
@@ -979,10 +1676,13 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
                 rt = scal[20];
                 __syncthreads();
             }
+            MDT_PROF_MARK(PH_SERT);
         }
         if (kp.need_et && kp.ess_ok) {
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
+            else if (n <= (long long)IND_MAXW * 64) et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem);
             else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem);
+            MDT_PROF_MARK(PH_IND);
         }
         if (tid == 0) {
             store_out<T>(kp.out_eb, p, eb);
@@ -992,6 +1692,7 @@ __global__ __launch_bounds__(NT) void mdt_kernel(KP kp) {
             store_out<T>(kp.out_rrank, p, jl_max(rt, rb)); // map(max, Rtail, Rbulk), src/ess_rhat.jl:419,622
         }
         __syncthreads();
+        MDT_PROF_MARK(PH_OUT);
     }
 }
 

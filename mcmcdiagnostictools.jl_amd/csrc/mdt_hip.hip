@@ -26,6 +26,7 @@ struct mdt_ctx {
     std::string err;
     // per-workgroup scratch
     unsigned int* r2buf = nullptr;
+    double* zbuf = nullptr;
     unsigned short* binbuf = nullptr;
     long long n_pad = 0;
     // normal-score table
@@ -35,6 +36,9 @@ struct mdt_ctx {
     long long ztab_cap = 0;
     // status word + nested chain indices
     int* status = nullptr;
+    unsigned long long* prof = nullptr; // [grid*16] phase cycle counters when MDT_PROF is set
+    KP* kp_ring = nullptr;              // device copies of the kernel parameters, one slot per launch
+    unsigned kp_next = 0;
     int* chain_inds = nullptr;
     int chain_inds_cap = 0;
     // host staging
@@ -45,6 +49,8 @@ struct mdt_ctx {
 };
 
 namespace {
+
+constexpr unsigned KP_RING = 64;
 
 int fail(mdt_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -66,9 +72,11 @@ int ensure_scratch(mdt_ctx* ctx, long long n) {
     if (n_pad > ctx->n_pad) {
         if (ctx->r2buf) (void)hipFree(ctx->r2buf);
         if (ctx->binbuf) (void)hipFree(ctx->binbuf);
-        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->n_pad = 0;
+        if (ctx->zbuf) (void)hipFree(ctx->zbuf);
+        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->n_pad = 0;
         HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)ctx->grid * n_pad * sizeof(unsigned int)));
         HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
+        HIP_TRY(hipMalloc((void**)&ctx->zbuf, (size_t)ctx->grid * n_pad * sizeof(double)));
         ctx->n_pad = n_pad;
     }
     return MDT_OK;
@@ -232,18 +240,22 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         kp.q_g[i] = g;
     }
     kp.ztab = ctx->ztab;
-    kp.r2buf = ctx->r2buf; kp.binbuf = ctx->binbuf; kp.n_pad = ctx->n_pad;
+    kp.r2buf = ctx->r2buf; kp.zbuf = ctx->zbuf; kp.binbuf = ctx->binbuf; kp.n_pad = ctx->n_pad;
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
     kp.chain_inds = ctx->chain_inds; kp.K = rq.K; kp.S = rq.S;
     kp.status = ctx->status;
+    kp.prof = ctx->prof;
 
     const unsigned grid = (unsigned)((P < ctx->grid) ? P : ctx->grid);
-    if (f32)
-        hipLaunchKernelGGL(mdt_kernel<float>, dim3(grid), dim3(NT), LDS_BYTES, st, kp);
-    else
-        hipLaunchKernelGGL(mdt_kernel<double>, dim3(grid), dim3(NT), LDS_BYTES, st, kp);
+    void (*kern)(const KP*) = f32 ? mdt_kernel<float> : mdt_kernel<double>;
+    // the parameter block travels through a small ring in device memory: the kernel reads it with
+    // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
+    KP* slot = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
+    if (ctx->kp_next % KP_RING == 0) HIP_TRY(hipStreamSynchronize(st)); // never overwrite a slot still in flight
+    HIP_TRY(hipMemcpyAsync(slot, &kp, sizeof(KP), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, st, (const KP*)slot);
     HIP_TRY(hipGetLastError());
 
     if (a->location == MDT_HOST) {
@@ -284,13 +296,29 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
     ctx->num_cu = prop.multiProcessorCount;
     ctx->grid = ctx->num_cu > 0 ? ctx->num_cu : 256; // one 1024-thread workgroup per CU (LDS-bound)
+    if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = v; } // diagnostics
     if (hipMalloc((void**)&ctx->status, sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
-    // > 64 KB of dynamic LDS needs the opt-in
-    if (hipFuncSetAttribute((const void*)mdt_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mdt_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
+    const void* kerns[] = {(const void*)mdt_kernel<double>, (const void*)mdt_kernel<float>};
+    for (const void* k : kerns) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+            (void)hipFree(ctx->status);
+            delete ctx;
+            return MDT_ERUNTIME;
+        }
+    }
+    if (hipMalloc((void**)&ctx->kp_ring, KP_RING * sizeof(KP)) != hipSuccess) {
         (void)hipFree(ctx->status);
         delete ctx;
-        return MDT_ERUNTIME;
+        return MDT_ENOMEM;
+    }
+    if (getenv("MDT_PROF")) {
+        if (hipMalloc((void**)&ctx->prof, (size_t)ctx->grid * 16 * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(ctx->prof, 0, (size_t)ctx->grid * 16 * sizeof(unsigned long long)) != hipSuccess) {
+            (void)hipFree(ctx->status);
+            delete ctx;
+            return MDT_ENOMEM;
+        }
     }
     *out = ctx;
     return MDT_OK;
@@ -302,8 +330,11 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     (void)hipDeviceSynchronize();
     if (ctx->r2buf) (void)hipFree(ctx->r2buf);
     if (ctx->binbuf) (void)hipFree(ctx->binbuf);
+    if (ctx->zbuf) (void)hipFree(ctx->zbuf);
     if (ctx->ztab) (void)hipFree(ctx->ztab);
     if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->prof) (void)hipFree(ctx->prof);
+    if (ctx->kp_ring) (void)hipFree(ctx->kp_ring);
     if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
@@ -385,6 +416,25 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out
     Req rq;
     rq.mode = 2; rq.basic = 1; rq.need_eb = 1; rq.out_eb = mcse_out; rq.want_ess = 1;
     return run(ctx, a, x, rq);
+}
+
+int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset) {
+    if (!ctx || !out16) return MDT_EARG;
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    if (!ctx->prof) return fail(ctx, MDT_EUNSUPPORTED, "phase counters are off (create the context with MDT_PROF=1 in the environment)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t cnt = (size_t)ctx->grid * 16;
+    unsigned long long* h = (unsigned long long*)malloc(cnt * sizeof(unsigned long long));
+    if (!h) return MDT_ENOMEM;
+    hipError_t e = hipMemcpy(h, ctx->prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        for (size_t i = 0; i < cnt; ++i) out16[i % 16] += h[i];
+        if (reset) e = hipMemset(ctx->prof, 0, cnt * sizeof(unsigned long long));
+    }
+    free(h);
+    if (e != hipSuccess) return fail(ctx, MDT_ERUNTIME, hipGetErrorString(e));
+    return MDT_OK;
 }
 
 int mdt_rank_normalize(mdt_ctx* ctx, const mdt_args* a, const void* x, int32_t fold, double* rank_out,

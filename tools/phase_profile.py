@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Diagnostics: where the fused kernel spends its cycles, by phase (needs a GPU).
+
+    MDT_PROF=1 python tools/phase_profile.py [--params 2560] [--draws 10000] [--chains 4]
+
+Reads the per-phase shader-clock totals the kernel accumulates when the context is created with
+MDT_PROF=1 (mdt_debug_phase_cycles) and prints each phase's share.  Shares, not durations: the
+stamps themselves perturb nothing but they are summed over all workgroups.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+os.environ.setdefault("MDT_PROF", "1")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import __graft_entry__ as g  # noqa: E402
+from bench import synth  # noqa: E402
+
+NAMES = {0: "load x -> registers", 1: "rank x (total)", 2: "series bulk (moments+autocov+Geyer)", 3: "rank |x-med| (total)",
+         4: "series tail (moments)", 5: "indicators (tail ESS)", 6: "outputs",
+         8: "  rank: sample+sort+splitters", 9: "  rank: histogram", 10: "  rank: scan+rounds", 11: "  rank: place",
+         12: "  rank: count", 13: "  zseries: loads+stores", 14: "  zseries: barrier", 15: "  zseries: products+reductions",
+         7: "  zseries: finalize"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--params", type=int, default=2560)
+    ap.add_argument("--draws", type=int, default=10000)
+    ap.add_argument("--chains", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    pkg = g.load_package()
+    x = synth(a.draws, a.chains, a.params, torch.device("cuda", 0), 1234).permute(2, 1, 0)
+    pkg.bulk_tail(x)
+    lib, h = pkg._lib.load(), pkg._lib.ctx(0)
+    buf = (ctypes.c_uint64 * 16)()
+    lib.mdt_debug_phase_cycles(h, buf, 1)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(a.reps):
+        pkg.bulk_tail(x, sync=False)
+    ev1.record()
+    torch.cuda.synchronize()
+    rc = lib.mdt_debug_phase_cycles(h, buf, 1)
+    assert rc == 0, rc
+    ms = ev0.elapsed_time(ev1) / a.reps
+    top = sum(buf[i] for i in range(7))  # slots 7.. are sub-phases that also advance the shared stamp
+    print(f"{a.draws}x{a.chains}x{a.params}: {ms:.3f} ms per call, {a.params / ms * 1e3:.0f} param-series/s")
+    for i in sorted(NAMES):
+        print(f"{NAMES[i]:42s} {100.0 * buf[i] / top:6.2f} %")
+
+
+if __name__ == "__main__":
+    main()
