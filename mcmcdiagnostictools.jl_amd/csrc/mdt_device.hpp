@@ -742,6 +742,8 @@ __device__ inline void series_combine(const KPT& kp, unsigned char* smem, int bl
             const double n2 = (double)(niter - k);
             const double sdiff = (2.0 * A[0] - aux[k] - aux[NLAGTAB + k] - 2.0 * A[k]) / dm;
             ma = W - sdiff / (2.0 * n2);
+        } else if (method == 1) {
+            ma = A[k] / dm * kp.cf; // mean_i(ac_k/ac_0 * var_i) * (niter-1)//niter, src/ess_rhat.jl:191-194
         } else {
             ma = A[k] / dm / dn;
         }
@@ -857,14 +859,21 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
             } else {
                 mu = mean_j[j];
             }
-            // pass 2: centred lag products
+            // pass 2: centred lag products; the sum of squares for var_j is taken per thread over the
+            // values it centres and reduced in a fixed order, so that it does not depend on the lag-block
+            // layout: rhat(x) == ess_rhat(x).rhat bit for bit (test/ess_rhat.jl:66-98, 167-204)
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            double sq = 0.0;
             const int halo = want_acov ? (int)k0 + 8 * G : 8; // ser[t + k] is read for k < k0 + 8G
             for (int ti = 0; ti < ntile; ++ti) {
                 const long long tau = (long long)ti * TL;
                 const int tlen = (int)((niter - tau < TL) ? niter - tau : TL);
                 if (ntile == 1 && block == 0) {
-                    for (int i = tid; i < tlen + halo; i += NT) ser[i] = (i < tlen) ? ser[i] - mu : 0.0;
+                    for (int i = tid; i < tlen + halo; i += NT) {
+                        const double cv = (i < tlen) ? ser[i] - mu : 0.0;
+                        ser[i] = cv;
+                        sq = fma(cv, cv, sq);
+                    }
                 } else {
                     __syncthreads();
                     for (int i0 = tid; i0 < tlen + halo; i0 += NT * 8) {
@@ -878,6 +887,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
                         for (int u = 0; u < 8; ++u) {
                             const int i = i0 + u * NT;
                             if (i < tlen + halo) ser[i] = v[u];
+                            if (i < tlen) sq = fma(v[u], v[u], sq);
                         }
                     }
                 }
@@ -905,6 +915,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
                     }
                 }
             }
+            const double S2 = (block == 0) ? wg_sum(sq, red) : 0.0;
             // reduce the wave partials in a fixed order
             {
                 const int w = tid >> 6, lane = tid & 63;
@@ -919,7 +930,10 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
                 if (tid < 8 * G && kq < kend) {
                     double sm = 0.0;
                     for (int q2 = 0; q2 < nseg; ++q2) sm += part[tid * nseg + q2];
-                    if (kq == 0) var_j[j] = sm / (double)(niter - 1); // Statistics.var(...; mean, corrected=true)
+                    if (kq == 0) {
+                        sm = S2;
+                        var_j[j] = sm / (double)(niter - 1); // Statistics.var(...; mean, corrected=true)
+                    }
                     A[kq] += sm;
                 }
                 __syncthreads();
@@ -1160,6 +1174,104 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
     return out;
 }
 
+
+// ------------------------------------------------------------------ series phase, FFTAutocovMethod
+// src/ess_rhat.jl:103-118 (cache), :130-152 (update!), :181-195 (query): per split chain the centred
+// series is zero-padded, transformed, |.|^2, transformed back, and the mean over chains of
+// ac_k / ac_0 * var_j * (niter-1)/niter is the lag-k autocovariance (NaN when a chain is constant:
+// 0/0, as in the reference).  Here: in-LDS radix-2 complex FFT, decimation in frequency forward
+// (natural -> bit-reversed), |.|^2 in place (order-free), decimation in time inverse (bit-reversed ->
+// natural), so no reordering pass is needed.  Pad length N = nextpow2(niter + maxlag + 1): only lags
+// <= maxlag are ever read (:482,563,590), and for those any N >= niter + maxlag + 1 gives the same
+// linear autocorrelation as the reference's nextprod([2,3], 2 niter - 1).
+constexpr int FFT_MAXN = 8192;                              // complex points resident in LDS (128 KiB)
+constexpr int OFF_FFT = OFF_AUX;                            // double2 fbuf[FFT_MAXN]
+static_assert(OFF_FFT + FFT_MAXN * 16 <= LDS_BYTES, "FFT buffer exceeds the LDS carve");
+
+template <class YF>
+MDT_PHASE SeriesOut series_fft_phase(const KP& kp_, YF Y, unsigned char* smem) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    Y.make_uniform();
+    const int tid = threadIdx.x;
+    double* scal = (double*)(smem + OFF_SCAL);
+    int* ints = (int*)(smem + OFF_INTS);
+    double* mean_j = (double*)(smem + OFF_MEAN);
+    double* var_j = (double*)(smem + OFF_VAR);
+    double* A = (double*)(smem + OFF_LAGA);
+    double2* fb = (double2*)(smem + OFF_FFT);
+    const long long niter = kp.niter, maxlag = kp.maxlag;
+    const int n = (int)niter, m = kp.m, s = kp.s, rem = kp.rem;
+    int N = 1, logN = 0;
+    while (N < n + (int)maxlag + 1) { N <<= 1; ++logN; }
+    SeriesOut out;
+
+    // mean_j / var_j were left in LDS by the moments sweep that ran just before (same expressions
+    // as every other path, so R-hat is bit-identical across autocov methods, test/ess_rhat.jl:228)
+    for (int k = tid; k < NLAGTAB; k += NT) A[k] = 0.0;
+    if (tid == 0) { ints[1] = 0; ints[2] = 0; }
+    __syncthreads();
+
+    for (int j = 0; j < m; ++j) {
+        const int c = j / s, kk = j - c * s;
+        const long long r0 = split_row0(kk, niter, rem);
+        const double mu = mean_j[j];
+        for (int i = tid; i < N; i += NT) {
+            double2 v;
+            v.x = (i < n) ? Y(c, r0 + i) - mu : 0.0;
+            v.y = 0.0;
+            fb[i] = v;
+        }
+        __syncthreads();
+        // forward, decimation in frequency
+        for (int half = N >> 1; half >= 1; half >>= 1) {
+            for (int b = tid; b < (N >> 1); b += NT) {
+                const int pos = b & (half - 1);
+                const int i = ((b - pos) << 1) + pos, i2 = i + half;
+                const double2 u = fb[i], v = fb[i2];
+                double sn, cs;
+                sincospi(-(double)pos / (double)half, &sn, &cs); // exp(-2 pi i pos / (2 half))
+                const double dx = u.x - v.x, dy = u.y - v.y;
+                double2 o1, o2;
+                o1.x = u.x + v.x; o1.y = u.y + v.y;
+                o2.x = dx * cs - dy * sn; o2.y = dx * sn + dy * cs;
+                fb[i] = o1; fb[i2] = o2;
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < N; i += NT) {
+            double2 v = fb[i];
+            v.x = fma(v.x, v.x, v.y * v.y);
+            v.y = 0.0;
+            fb[i] = v;
+        }
+        __syncthreads();
+        // inverse (unnormalised: only ratios are used), decimation in time
+        for (int half = 1; half <= (N >> 1); half <<= 1) {
+            for (int b = tid; b < (N >> 1); b += NT) {
+                const int pos = b & (half - 1);
+                const int i = ((b - pos) << 1) + pos, i2 = i + half;
+                const double2 u = fb[i], v = fb[i2];
+                double sn, cs;
+                sincospi((double)pos / (double)half, &sn, &cs);
+                double2 t, o1, o2;
+                t.x = v.x * cs - v.y * sn; t.y = v.x * sn + v.y * cs;
+                o1.x = u.x + t.x; o1.y = u.y + t.y;
+                o2.x = u.x - t.x; o2.y = u.y - t.y;
+                fb[i] = o1; fb[i2] = o2;
+            }
+            __syncthreads();
+        }
+        if (tid <= maxlag) A[tid] += fb[tid].x / fb[0].x * var_j[j]; // :192, summed over chains in order
+        __syncthreads();
+    }
+    if (tid == 0) series_combine(kp, smem, 1 /* moments already combined */, maxlag + 1, true);
+    __syncthreads();
+    out.rhat = scal[2];
+    out.ess = scal[3];
+    __syncthreads();
+    return out;
+}
+
 // ------------------------------------------------------------------ indicator (tail ESS) phase
 __device__ __forceinline__ unsigned long long bits_at(const unsigned long long* __restrict__ w, long long pos, int nw) {
     // 64 bits starting at bit `pos` of the little-endian bit stream w[0..nw)
@@ -1241,7 +1353,8 @@ MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, doubl
                         }
                         // n^2 * sum_t (I_t - mu)(I_{t+k} - mu) with mu = S/n, exact in int64
                         const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
-                        const double ck = (double)N / (dn * dn);
+                        double ck = (double)N / (dn * dn);
+                        if (kp.method == 1 && k > 0 && (Sx == 0 || Sx == niter)) ck = __builtin_nan(""); // 0/0, :192
                         icov[ind * NLAGTAB + k] += ck;
                         // variogram numerator (BDA, src/ess_rhat.jl:204-212): the mean cancels in
                         // c_t - c_{t+k}, so sum_t (I_t - I_{t+k})^2 = #(I_t != I_{t+k}) = H + T - 2A
@@ -1402,6 +1515,9 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
                     }
                     const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
                     ck = (double)N / (dn * dn);
+                    // FFTAutocovMethod normalises by the lag-0 value of the same chain: 0/0 -> NaN for a
+                    // constant split chain (src/ess_rhat.jl:192); Sx in {0, niter} <=> constant
+                    if (kp.method == 1 && k > 0 && (Sx == 0 || Sx == niter)) ck = __builtin_nan("");
                     dk = (double)(Hk + Tk - 2 * Ak);
                     if (k == 0) imean[(u & 1) * MAXM + jb + (u >> 1)] = (double)Sx / dn;
                 }
@@ -1562,7 +1678,13 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
 
         if (kp.basic && kp.mode != 3) {
             const bool acov = kp.need_eb && kp.ess_ok;
-            const SeriesOut so = series_phase(kp, YX, acov, smem);
+            SeriesOut so;
+            if (acov && kp.method == 1) {
+                (void)series_phase(kp, YX, false, smem); // moments -> mean_j / var_j / R-hat
+                so = series_fft_phase(kp, YX, smem);
+            } else {
+                so = series_phase(kp, YX, acov, smem);
+            }
             double ess = acov ? so.ess : nan;
             if (kp.mode == 1) {
                 if (tid == 0) store_out<T>(kp.out_rb, p, nested_combine());
@@ -1654,7 +1776,13 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
         double eb = nan, rb = nan, et = nan, rt = nan;
         if (kp.need_eb || kp.need_rb) {
             const bool acov = kp.need_eb && kp.ess_ok;
-            const SeriesOut so = zfast ? series_z_phase(kp, zb, acov, smem) : series_phase(kp, YZ, acov, smem);
+            SeriesOut so;
+            if (acov && kp.method == 1) {
+                (void)(zfast ? series_z_phase(kp, zb, false, smem) : series_phase(kp, YZ, false, smem));
+                so = series_fft_phase(kp, YZ, smem);
+            } else {
+                so = zfast ? series_z_phase(kp, zb, acov, smem) : series_phase(kp, YZ, acov, smem);
+            }
             rb = (kp.mode == 1) ? 0.0 : so.rhat;
             if (acov) eb = so.ess;
             if (kp.mode == 1) {

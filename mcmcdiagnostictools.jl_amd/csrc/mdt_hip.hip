@@ -140,8 +140,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (maxlag > MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     if (rq.need_et && D > (long long)BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
-    if (a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok)
-        return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod is not implemented on the device yet");
+    if (a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok && niter + maxlag + 1 > FFT_MAXN)
+        return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod on the device needs draws/split_chains + maxlag + 1 <= 8192 "
+                                           "(the in-LDS transform); use AutocovMethod for longer chains");
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)a->stream;

@@ -12,7 +12,7 @@ from conftest import ar1, assert_close, golden_names, load_golden
 pytestmark = pytest.mark.gpu
 
 RTOL64 = 1e-9
-FFT_ON_DEVICE = False  # FFTAutocovMethod returns MDT_EUNSUPPORTED until the device FFT lands
+FFT_ON_DEVICE = True
 KINDS = ["rank", "bulk", "tail", "basic"]
 
 
@@ -200,3 +200,53 @@ def test_nan_semantics(pkg):
     assert_close(R, want, RTOL64)
     with pytest.raises(pkg.ArgumentError):
         pkg.ess(dev(x), kind="tail")
+
+
+def test_methods_agree_and_rhat_is_method_independent(pkg, methods):
+    """test/ess_rhat.jl:210-240: default == AutocovMethod; FFT ≈ direct (rtol sqrt(eps)); R-hat
+    identical (==) across all three methods and equal to rhat(x) for every kind"""
+    rng = np.random.default_rng(21)
+    for scale, nchains, split in ((1, 1, 1), (50, 10, 2), (100, 4, 2)):
+        x = scale * rng.standard_normal((2000, nchains, 8))
+        xd = dev(x)
+        for kind in KINDS:
+            S0, R0 = pkg.ess_rhat(xd, kind=kind, split_chains=split)
+            Sd, Rd = pkg.ess_rhat(xd, kind=kind, split_chains=split, autocov_method=methods["direct"])
+            Sf, Rf = pkg.ess_rhat(xd, kind=kind, split_chains=split, autocov_method=methods["fft"])
+            Sb, Rb = pkg.ess_rhat(xd, kind=kind, split_chains=split, autocov_method=methods["bda"])
+            assert np.array_equal(host(S0), host(Sd))
+            assert_close(host(Sf), host(Sd), 1.5e-8, f"fft vs direct {kind}")
+            Ronly = host(pkg.rhat(xd, kind=kind, split_chains=split))
+            for R in (R0, Rd, Rf, Rb):
+                assert np.array_equal(host(R), Ronly), kind
+
+
+def test_long_chain_shape(pkg, methods):
+    """BASELINE config 3 per-parameter shape (100_000 draws x 8 chains), 3 params: the multi-round
+    ranking (n = 800_000 > LDS chunk) and the tiled series path against the oracle"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(33)
+    x = np.concatenate([rng.standard_normal((100_000, 8, 2)), ar1(0.9, 100_000, 8, 1, rng)], axis=2)
+    got = [host(o) for o in pkg.bulk_tail(dev(x))]
+    want = co.bulk_tail(x)
+    for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+        assert_close(a, b, RTOL64, nm)
+    with pytest.raises(NotImplementedError):  # the in-LDS FFT holds 8192 points; says so instead of guessing
+        pkg.ess(dev(x), kind="bulk", autocov_method=methods["fft"])
+
+
+def test_f32_other_methods_and_sizes(pkg, methods):
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(44)
+    x = ar1(0.5, 2500, 16, 5, rng).astype(np.float32)  # n = 40_000 float32
+    xd = dev(x)
+    for kind in ("bulk", "tail"):
+        for m in ("direct", "fft", "bda"):
+            S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[m])
+            We, Wr = co.ess_rhat(x, kind=kind, autocov=m)
+            assert_close(host(S), We, 1e-6, f"{kind} {m}")
+            assert_close(host(R), Wr, 1e-6, f"{kind} {m}")
+    ids = np.repeat(np.arange(4), 4)
+    inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
+    assert_close(host(pkg.rhat_nested(xd, ids)), co.rhat_nested(x, inds), 1e-6)
+    assert_close(host(pkg.mcse(xd)), co.mcse_mean(x), 1e-6)
