@@ -1,0 +1,147 @@
+# MCMCDiagnosticToolsROC.jl -- thin Julia shim over libmdt_hip.so (include/mdt_hip.h).
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: Julia is not available in the build image.  It shows the
+# reference-side binding a maintainer would add: same function names, keyword arguments, array
+# convention and error types as MCMCDiagnosticTools.jl (src/MCMCDiagnosticTools.jl:17-25), one
+# `ccall` per request.  The tested host mirror is the Python package next to it.
+module MCMCDiagnosticToolsROC
+
+using Statistics: Statistics
+
+export ess, rhat, ess_rhat, rhat_nested, mcse
+export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
+
+const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")
+
+abstract type AbstractAutocovMethod end
+struct AutocovMethod <: AbstractAutocovMethod end      # src/ess_rhat.jl:38
+struct FFTAutocovMethod <: AbstractAutocovMethod end   # src/ess_rhat.jl:55
+struct BDAAutocovMethod <: AbstractAutocovMethod end   # src/ess_rhat.jl:73
+_code(::AutocovMethod) = Cint(0)
+_code(::FFTAutocovMethod) = Cint(1)
+_code(::BDAAutocovMethod) = Cint(2)
+_code(m::AbstractAutocovMethod) =
+    throw(ArgumentError("$(typeof(m)) is a CPU plugin; use MCMCDiagnosticTools.jl for it"))
+
+# mirrors `struct mdt_args` field for field
+struct MdtArgs
+    draws::Int64
+    chains::Int64
+    params::Int64
+    dtype::Int32      # 0 Float64, 1 Float32
+    location::Int32   # 0 host, 1 device
+    kind::Int32       # 0 basic 1 bulk 2 tail 3 rank
+    outputs::Int32    # 1 ESS | 2 RHAT
+    autocov::Int32
+    split_chains::Int32
+    relative::Int32
+    sync::Int32
+    maxlag::Int64
+    tail_prob::Float64
+    stream::Ptr{Cvoid}
+end
+
+const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
+function ctx()
+    if _ctx[] == C_NULL
+        rc = ccall((:mdt_ctx_create, libmdt), Cint, (Ref{Ptr{Cvoid}}, Cint), _ctx, 0)
+        rc == 0 || error("mdt_ctx_create failed with status $rc (no MI355X visible?)")
+    end
+    return _ctx[]
+end
+
+function _check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:mdt_last_error, libmdt), Cstring, (Ptr{Cvoid},), ctx()))
+    rc == 1 && throw(ArgumentError(msg))
+    rc == 2 && throw(DomainError(0, msg))
+    rc == 3 && throw(DimensionMismatch(msg))
+    rc == 6 && throw(ArgumentError("unsupported on the device path: " * msg))
+    error("libmdt_hip status $rc: $msg")
+end
+
+const _KIND = Dict(:basic => 0, :bulk => 1, :tail => 2, :rank => 3)
+
+# (draws, chains, params...) -> (T, dense 3-d array) exactly like src/utils.jl:197-215
+function _params_array(x::AbstractArray)
+    T = float(eltype(x))
+    T in (Float32, Float64) || (T = Float64)
+    x3 = reshape(x, size(x, 1), size(x, 2), :)
+    return T, convert(Array{T,3}, x3)
+end
+_maybescalar(x::AbstractArray{<:Any,0}) = x[]
+_maybescalar(x::AbstractArray) = x
+_out(x, v) = _maybescalar(reshape(v, size(x)[3:end]...))
+
+function _ess_rhat(x, kind::Symbol, outputs; relative::Bool=false,
+                   autocov_method::AbstractAutocovMethod=AutocovMethod(), split_chains::Int=2,
+                   maxlag::Int=250, tail_prob::Real=1//10)
+    T, x3 = _params_array(x)
+    D, C, P = size(x3)
+    niter = D ÷ split_chains
+    (outputs & 1) != 0 && !(niter > 4) &&
+        @warn "number of draws after splitting must be >4 but is $niter. ESS cannot be computed."
+    S = Vector{T}(undef, P); R = Vector{T}(undef, P)
+    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, _KIND[kind], outputs, _code(autocov_method),
+                split_chains, relative, 1, maxlag, Float64(tail_prob), C_NULL)
+    GC.@preserve x3 S R begin
+        _check(ccall((:mdt_ess_rhat, libmdt), Cint,
+                     (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                     ctx(), a, x3, (outputs & 1) != 0 ? pointer(S) : C_NULL,
+                     (outputs & 2) != 0 ? pointer(R) : C_NULL))
+    end
+    return _out(x, S), _out(x, R)
+end
+
+function ess(x::AbstractArray{<:Real}; kind=:bulk, kwargs...)
+    kind === Statistics.mean && return first(_ess_rhat(x, :basic, 1; kwargs...))  # src/ess_rhat.jl:629
+    kind isa Symbol && haskey(_KIND, kind) && kind !== :rank ||
+        throw(ArgumentError("the `kind` `$kind` is not supported by `ess`"))
+    return first(_ess_rhat(x, kind, 1; kwargs...))
+end
+function rhat(x::AbstractArray{<:Real}; kind::Symbol=:rank, split_chains::Int=2)
+    haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat`"))
+    return last(_ess_rhat(x, kind, 2; split_chains))
+end
+function ess_rhat(x::AbstractArray{<:Real}; kind::Symbol=:rank, kwargs...)
+    haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `ess_rhat`"))
+    S, R = _ess_rhat(x, kind, 3; kwargs...)
+    return (; ess=S, rhat=R)
+end
+
+function rhat_nested(x::AbstractArray{<:Real}, superchain_ids::AbstractVector; kind::Symbol=:rank,
+                     split_chains::Int=2)
+    ndims(x) >= 2 || throw(ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`"))
+    length(superchain_ids) == size(x, 2) || throw(DimensionMismatch("`superchain_ids` has length $(length(superchain_ids)) but `samples` has $(size(x, 2)) chains"))
+    ids = sort(unique(superchain_ids))
+    length(ids) >= 2 || throw(ArgumentError("at least 2 superchains are required, got $(length(ids))"))
+    groups = [findall(==(i), superchain_ids) for i in ids]
+    allequal(length, groups) || throw(ArgumentError("all superchains must contain the same number of chains"))
+    inds = Int32.(reduce(hcat, groups) .- 1)             # K x S, 0-based, column-major
+    haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat_nested`"))
+    T, x3 = _params_array(x)
+    D, C, P = size(x3)
+    R = Vector{T}(undef, P)
+    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, _KIND[kind], 2, 0, split_chains, 0, 1, 250, 0.1, C_NULL)
+    GC.@preserve x3 R inds begin
+        _check(ccall((:mdt_rhat_nested, libmdt), Cint,
+                     (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}),
+                     ctx(), a, x3, inds, size(inds, 1), size(inds, 2), R))
+    end
+    return _out(x, R)
+end
+
+function mcse(x::AbstractArray{<:Real}; kind=Statistics.mean, autocov_method=AutocovMethod(),
+              split_chains::Int=2, maxlag::Int=250)
+    kind === Statistics.mean || throw(ArgumentError("only kind=mean is on the device path"))
+    T, x3 = _params_array(x)
+    D, C, P = size(x3)
+    out = Vector{T}(undef, P)
+    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL)
+    GC.@preserve x3 out begin
+        _check(ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
+    end
+    return _out(x, out)
+end
+
+end # module
