@@ -1067,8 +1067,8 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
     long long k0 = 0;
     int block = 0;
     while (true) {
-        const int G = (block == 0) ? 2 : 4;
-        long long kend = (block == 0) ? 16 : k0 + 32;
+        const int G = 4;                 // 32 lags per block: lag-groups of 8 x 4 time-segments
+        long long kend = k0 + 32;
         if (kend > maxlag + 1) kend = maxlag + 1;
         const int nseg = NWAVE / G;
         const int halo = (int)k0 + 8 * G;
