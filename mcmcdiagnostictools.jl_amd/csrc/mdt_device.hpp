@@ -117,7 +117,7 @@ struct KP {
     void* z_out;                // stage: [P*n] normal scores (T)
     const int* chain_inds;      // nested: K x S (device)
     int K, S;
-    int* status;                // device status word (bit0: rounds overflow, bit1: NaN hit quantile)
+    int* status;                // device status words: [0] bit0 rounds overflow, bit1 NaN hit quantile; [1] next-parameter ticket
     unsigned long long* prof;   // optional [grid*16] phase cycle counters (diagnostics), or null
 };
 
@@ -1621,7 +1621,15 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
     const double nan = __builtin_nan("");
     if (kp.prof && tid == 0) *(long long*)(smem + OFF_PROFT) = clock64();
 
-    for (long long p = blockIdx.x; p < kp.P; p += gridDim.x) {
+    // parameters are handed out dynamically (one atomic ticket per parameter): slowly mixing
+    // parameters need more lag blocks than well-mixed ones, and a static stride leaves CUs idle
+    int* tick = (int*)(smem + OFF_INTS) + 11;
+    while (true) {
+        if (tid == 0) *tick = atomicAdd(kp.status + 1, 1);
+        __syncthreads();
+        const long long p = *tick;
+        __syncthreads();
+        if (p >= kp.P) break;
         const T* __restrict__ xp = (const T*)kp.x + p * n;
         const SrcPlain<T> VX{(const MDT_GA T*)xp};
         const SerX<T> YX{(const MDT_GA T*)xp, D};

@@ -199,7 +199,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         }
         HIP_TRY(hipMemcpyAsync(ctx->chain_inds, rq.chain_inds, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
 
     KP kp;
     memset(&kp, 0, sizeof(kp));
@@ -298,7 +298,7 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     ctx->num_cu = prop.multiProcessorCount;
     ctx->grid = ctx->num_cu > 0 ? ctx->num_cu : 256; // one 1024-thread workgroup per CU (LDS-bound)
     if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = v; } // diagnostics
-    if (hipMalloc((void**)&ctx->status, sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
+    if (hipMalloc((void**)&ctx->status, 2 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
     // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
     const void* kerns[] = {(const void*)mdt_kernel<double>, (const void*)mdt_kernel<float>};
     for (const void* k : kerns) {
