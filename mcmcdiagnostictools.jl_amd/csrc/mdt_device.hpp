@@ -1071,14 +1071,19 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
         long long kend = k0 + 32;
         if (kend > maxlag + 1) kend = maxlag + 1;
         const int nseg = NWAVE / G;
-        const int halo = (int)k0 + 8 * G;
+        const int halo = (int)k0 + 8 * G + 2;
         const int g = w % G, q = w / G;
-        const int seglen = (n + nseg - 1) / nseg;
+        const int seglen = (((n + nseg - 1) / nseg) + 1) & ~1; // even, so that every lane's pair is 16-byte aligned
         const int t0 = q * seglen;
         const int t1 = (t0 + seglen < n) ? t0 + seglen : n;
         const int kb = (int)k0 + 8 * g;
 
-        // finalize split chain j from the wave partials: runs on the lanes that own the lags
+        // Lagged products are linear in the chain, and only their SUM over chains is ever used
+        // (src/ess_rhat.jl:170-178), so the accumulators run across all split chains and are reduced
+        // once per sweep; per chain only the small centring terms are finalised (by the lanes that
+        // own the lags) from S1, S2 and the first / last values.
+        double corr = 0.0; // this lane's lag: sum over chains of the centring correction (or C_0 for lag 0)
+        double bda_h = 0.0, bda_t = 0.0;
         auto finalize = [&](int j) {
             const int b3 = j % 3;
             const double* pp = zpart + b3 * ZPW;
@@ -1086,34 +1091,33 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             const double* et = eh + SZ_EDGE;
             const long long kq = k0 + tid;
             if (tid < 8 * G && kq < kend) {
-                double P = 0.0, S1 = 0.0, S2 = 0.0;
-                for (int q2 = 0; q2 < nseg; ++q2) P += pp[tid * nseg + q2];
+                double S1 = 0.0, S2 = 0.0;
                 for (int q2 = 0; q2 < NWAVE; ++q2) { S1 += pp[NWAVE * 8 + q2]; S2 += pp[NWAVE * 9 + q2]; }
                 const double mu = S1 / (double)n;
                 double head = 0.0, tail = 0.0, hsq = 0.0, tsq = 0.0;
                 const int kk2 = (int)kq < he ? (int)kq : he;
                 for (int t = 0; t < kk2; ++t) {
-                    const double a = eh[t], b = et[he - 1 - t];
-                    head += a; tail += b;
-                    hsq = fma(a, a, hsq); tsq = fma(b, b, tsq);
+                    const double a2 = eh[t], b2 = et[he - 1 - t];
+                    head += a2; tail += b2;
+                    hsq = fma(a2, a2, hsq); tsq = fma(b2, b2, tsq);
                 }
-                double C;
                 if (kq == 0) {
-                    C = S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
+                    const double C = S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
                     var_j[j] = C / (double)(n - 1);
                     mean_j[j] = zk[b3] + mu;
+                    corr += C;
                 } else {
-                    C = P - mu * ((S1 - tail) + (S1 - head)) + (double)(n - kq) * mu * mu;
+                    corr += (double)(n - kq) * mu * mu - mu * ((S1 - tail) + (S1 - head));
                 }
-                A[kq] += C;
                 if (method == 2) {
                     // variogram pieces on centred values c = u - mu: sum_{t<k} c_t^2 = hsq - 2 mu head + k mu^2
-                    aux[kq] += hsq - 2.0 * mu * head + (double)kk2 * mu * mu;
-                    aux[NLAGTAB + kq] += tsq - 2.0 * mu * tail + (double)kk2 * mu * mu;
+                    bda_h += hsq - 2.0 * mu * head + (double)kk2 * mu * mu;
+                    bda_t += tsq - 2.0 * mu * tail + (double)kk2 * mu * mu;
                 }
             }
         };
 
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         issue_loads(0);
         for (int j = 0; j < m; ++j) {
             double* buf = zser + (j & 1) * SZ;
@@ -1143,24 +1147,46 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             __syncthreads();
             MDT_PROF_MARK(14); // barrier
             if (j + 1 < m) issue_loads(j + 1);
-            // lagged products of this wave's t-segment
-            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int t = t0 + lane; t < t1; t += 64) {
-                const double a = buf[t];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] = fma(a, buf[t + kb + i], acc[i]);
+            {
+                // two consecutive t per lane, 16-byte LDS reads (full LDS rate): 6 reads feed 16 FMAs
+                const double2* b2 = (const double2*)buf;
+                for (int t = t0 + 2 * lane; t < t1; t += 128) {
+                    const double2 a2 = b2[t >> 1];
+                    const int pq = (t + kb) >> 1;
+                    const double2 w0 = b2[pq], w1 = b2[pq + 1], w2 = b2[pq + 2], w3 = b2[pq + 3], w4 = b2[pq + 4];
+                    acc[0] = fma(a2.x, w0.x, acc[0]); acc[0] = fma(a2.y, w0.y, acc[0]);
+                    acc[1] = fma(a2.x, w0.y, acc[1]); acc[1] = fma(a2.y, w1.x, acc[1]);
+                    acc[2] = fma(a2.x, w1.x, acc[2]); acc[2] = fma(a2.y, w1.y, acc[2]);
+                    acc[3] = fma(a2.x, w1.y, acc[3]); acc[3] = fma(a2.y, w2.x, acc[3]);
+                    acc[4] = fma(a2.x, w2.x, acc[4]); acc[4] = fma(a2.y, w2.y, acc[4]);
+                    acc[5] = fma(a2.x, w2.y, acc[5]); acc[5] = fma(a2.y, w3.x, acc[5]);
+                    acc[6] = fma(a2.x, w3.x, acc[6]); acc[6] = fma(a2.y, w3.y, acc[6]);
+                    acc[7] = fma(a2.x, w3.y, acc[7]); acc[7] = fma(a2.y, w4.x, acc[7]);
+                }
             }
+            MDT_PROF_MARK(15); // lag products
+            if (j > 0) finalize(j - 1); // its S1 / S2 / edges were complete before this iteration's barrier
+            MDT_PROF_MARK(7);  // finalize
+        }
+        {
+            double* pp = zpart; // lag partials of the whole sweep (the S1/S2 slots of buffer 0 are not touched)
+            __syncthreads();
+            finalize(m - 1);
+            __syncthreads();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const double r = wave_sum(acc[i]);
                 if (lane == 0) pp[(g * 8 + i) * nseg + q] = r;
             }
-            MDT_PROF_MARK(15); // lag products + wave reductions
-            if (j > 0) finalize(j - 1); // its partials were complete before this iteration's barrier
-            MDT_PROF_MARK(7);  // finalize
+            __syncthreads();
+            const long long kq = k0 + tid;
+            if (tid < 8 * G && kq < kend) {
+                double P = 0.0;
+                for (int q2 = 0; q2 < nseg; ++q2) P += pp[tid * nseg + q2];
+                A[kq] += (kq == 0) ? corr : P + corr;
+                if (method == 2) { aux[kq] += bda_h; aux[NLAGTAB + kq] += bda_t; }
+            }
         }
-        __syncthreads();
-        finalize(m - 1);
         __syncthreads();
         if (tid == 0) series_combine(kp, smem, block, kend, true);
         __syncthreads();
