@@ -41,7 +41,7 @@ constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless 
 constexpr int NBIN = NREG + 4;
 constexpr int CH = 13760;           // elements of bin-ordered data staged in LDS per round
 constexpr int GRID = 2048;          // uniform cells over [min sample, max sample] that seed the splitter search
-constexpr int MAXROUNDS = 320;      // => n <= ~4.4M elements per parameter
+constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
 constexpr int TL = 8192;            // series tile (elements of one split chain resident in LDS)
 constexpr int HALO = 1040;          // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
 constexpr int MAXLAG_CAP = 1000;
@@ -59,7 +59,8 @@ constexpr int OFF_WTOT = OFF_INTS + 24 * 4;               // uint32 wtot[16]
 constexpr int OFF_RLO = OFF_WTOT + 16 * 4;                // int rlo[MAXROUNDS]
 constexpr int OFF_RHI = OFF_RLO + MAXROUNDS * 4;          // int rhi[MAXROUNDS]
 constexpr int OFF_RBASE = OFF_RHI + MAXROUNDS * 4;        // uint32 rbase[MAXROUNDS]
-constexpr int OFF_MEAN = OFF_RBASE + MAXROUNDS * 4;       // double mean_j[MAXM]
+constexpr int OFF_RCUR = OFF_RBASE + MAXROUNDS * 4;       // uint32 rcur[MAXROUNDS]: fill level of each round's segment
+constexpr int OFF_MEAN = ((OFF_RCUR + MAXROUNDS * 4 + 7) / 8) * 8; // double mean_j[MAXM]
 constexpr int OFF_VAR = OFF_MEAN + MAXM * 8;              // double var_j[MAXM]
 constexpr int OFF_BIG = ((OFF_VAR + MAXM * 8 + 15) / 16) * 16;
 // rank phase view of the big region
@@ -100,6 +101,7 @@ struct KP {
     int ess_ok;                 // niter > 4
     int relative;
     int fold;                   // rank_normalize stage: rank |x - median| instead of x
+    int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
     double ntotal;              // niter * m
@@ -109,6 +111,8 @@ struct KP {
     const double* ztab;         // normal scores by doubled rank, [2n+1]
     unsigned int* r2buf;        // per-workgroup scratch: doubled ranks, stride n_pad (streaming variant)
     double* zbuf;               // per-workgroup scratch: normal scores (or doubled ranks) in time order, stride n_pad
+    double* xsbuf;              // per-workgroup scratch: values grouped by round (segment r = sorted positions of round r)
+    unsigned short* bsbuf;      // per-workgroup scratch: bin ids in the same grouped order
     unsigned short* binbuf;     // per-workgroup scratch: bin ids, stride n_pad
     long long n_pad;
     void* out_eb; void* out_rb; void* out_et; void* out_rt; // [P] of T, or null
@@ -661,6 +665,295 @@ MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* s
             if (v != v) {
                 unsigned less = nn;
                 for (long long i = 0; i < e; ++i) { const double y = vg(i); less += (y != y) ? 1u : 0u; }
+                const unsigned r2 = 2u * less + 2u;
+                zout[e] = store_r2 ? (double)r2 : ztab[r2];
+                for (int t = 0; t < ntgt; ++t)
+                    if (tpos[t] == less) ostat[t] = __builtin_nan("");
+            }
+        }
+    }
+    if (tid == 0) ints[9] = (nn < (unsigned)n) ? 1 : 0;
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ rank phase, partitioned rounds
+// Same ranking as rank_phase_b, but the rounds do not re-stream the whole slice: after the histogram
+// one PARTITION pass appends every element (value, original index, bin) to the segment of its round
+// -- segment r is exactly the range of sorted positions [rbase[r], rbase[r] + cnt_r) -- with one LDS
+// atomic per wave per round present in the wave (ballot + mbcnt), so the global writes are runs of
+// consecutive addresses.  A round then loads its own segment (one batch of <= 14 elements per thread),
+// places, counts densely, and scatters the scores straight from registers to time order.
+// Traffic is O(n) for any n (rank_phase_b is O(n * rounds)) and every element is touched once per step.
+template <class VG>
+MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
+                            unsigned short* binbuf_, double* xsbuf_, unsigned short* bsbuf_, int ntgt_, int store_r2_) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    vg.make_uniform();
+    const long long n = uni(n_);
+    const int ntgt = uni(ntgt_), store_r2 = uni(store_r2_);
+    MDT_GA double* zout = uniptr_g(zout_);
+    MDT_GA unsigned* esbuf = uniptr_g(esbuf_);
+    MDT_GA unsigned short* binbuf = uniptr_g(binbuf_);
+    MDT_GA double* xsbuf = uniptr_g(xsbuf_);
+    MDT_GA unsigned short* bsbuf = uniptr_g(bsbuf_);
+    const long long step = (long long)NT * UB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const MDT_GA double* ztab = (const MDT_GA double*)kp.ztab;
+    double* ostat = (double*)(smem + OFF_OSTAT);
+    double* scal = (double*)(smem + OFF_SCAL);
+    unsigned* tpos = (unsigned*)(smem + OFF_TPOS);
+    int* ints = (int*)(smem + OFF_INTS);
+    unsigned* wtot = (unsigned*)(smem + OFF_WTOT);
+    int* rlo = (int*)(smem + OFF_RLO);
+    int* rhi = (int*)(smem + OFF_RHI);
+    unsigned* rbase = (unsigned*)(smem + OFF_RBASE);
+    unsigned* rcur = (unsigned*)(smem + OFF_RCUR);
+    double* spl_t = (double*)(smem + OFF_SPLT);
+    double* spl_s = (double*)(smem + OFF_SPLS);
+    unsigned* cur = (unsigned*)(smem + OFF_CUR);
+    unsigned* lut = (unsigned*)(smem + OFF_LUT);
+    double* chunk = (double*)(smem + OFF_CHUNK);
+
+    // ---- sample -> sorted -> splitters -> grid LUT
+    {
+        const long long items = (n + NT - 1) / NT;
+        long long js = tid % items;
+        if (js * NT + tid >= n && js > 0) --js;
+        long long es = js * NT + tid;
+        if (es >= n) es = (long long)(tid % n);
+        double v = vg(es);
+        if (v != v) v = __builtin_inf();
+        v = wg_bitonic_sort(v, chunk);
+        if ((tid & 3) == 0) spl_t[tid >> 2] = v;
+        if (tid == NT - 1) spl_t[K1] = v;
+        for (int b = tid; b < NBIN + 1; b += NT) cur[b] = 0u;
+        __syncthreads();
+        const double t0 = spl_t[0], top = spl_t[K1];
+        double ginv = (double)GRID / (top - t0);
+        if (!(ginv > 0.0) || !(ginv < __builtin_inf())) ginv = 0.0; // degenerate range: one cell, full search
+        if (tid < K1) {
+            const double w = spl_t[tid + 1] - spl_t[tid];
+            double sc = (w > 0.0 && w < __builtin_inf()) ? (double)(FINE - 1) / w : 0.0;
+            if (!(sc < __builtin_inf())) sc = 0.0;
+            spl_s[tid] = sc;
+        }
+        for (int c = tid; c < GRID; c += NT) {
+            int h[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cc = c - 1 + q;
+                int lo = 0, hi = K1 - 1;
+                if (cc < 0) hi = 0;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const double tm = spl_t[mid];
+                    const bool ok = (tm < top) ? (cell_of(tm, t0, ginv) <= cc) : false;
+                    if (ok) lo = mid; else hi = mid - 1;
+                }
+                h[q] = lo;
+            }
+            lut[c] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        }
+        if (tid == 0) { scal[21] = t0; scal[22] = top; scal[23] = ginv; }
+        __syncthreads();
+    }
+    BinCtx bc;
+    bc.t0 = scal[21]; bc.top = scal[22]; bc.ginv = scal[23];
+    MDT_PROF_MARK(PH_R_SAMPLE);
+
+    // ---- 1. histogram (the HBM read of x); bin ids kept for the partition pass
+    for (long long e0 = tid; e0 < n; e0 += step) {
+        double xb[UB];
+        int bq[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; xb[u] = (e < n) ? vg(e) : __builtin_nan(""); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) bq[u] = bin_of_fast(xb[u], bc, spl_t, spl_s, lut); // padding -> BIN_NAN
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cur[bq[u]], 1u); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; if (e < n) binbuf[e] = (unsigned short)bq[u]; }
+    }
+    __syncthreads();
+    MDT_PROF_MARK(PH_R_HIST);
+    // ---- 2. starts and rounds
+    wg_exscan_bins(cur, wtot, (unsigned)n);
+    if (tid == 0) {
+        int nr = 0, b = 0;
+        const unsigned nn = cur[BIN_NAN];
+        while (b < BIN_NAN && cur[b] < nn) {
+            if (nr >= MAXROUNDS) { atomicOr(kp.status, 1); break; }
+            const unsigned base = cur[b];
+            int lo = b, hi = BIN_NAN;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (cur[mid] - base <= (unsigned)CH) lo = mid; else hi = mid - 1;
+            }
+            rbase[nr] = base;
+            rlo[nr] = b;
+            rcur[nr] = 0u;
+            if (lo == b) { rhi[nr] = -(b + 1) - 1; b = b + 1; } // a single bin larger than the chunk
+            else { rhi[nr] = lo; b = lo; }
+            ++nr;
+        }
+        ints[0] = nr;
+        ints[10] = (int)nn;
+    }
+    __syncthreads();
+    MDT_PROF_MARK(PH_R_SCAN);
+    const int nr = ints[0];
+    // ---- 3. partition: append (value, index, bin) to the segment of the element's round
+    for (long long e0 = tid; e0 < n; e0 += step) {
+        double xb[UB];
+        int bq[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const long long e = e0 + (long long)u * NT;
+            bq[u] = (e < n) ? (int)binbuf[e] : BIN_NAN;
+            xb[u] = (e < n) ? vg(e) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int b = bq[u];
+            int r = -1;
+            if (b < BIN_NAN) { // round of the bin: last r with rlo[r] <= b
+                int lo2 = 0, hi2 = nr - 1;
+                while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (rlo[mid] <= b) lo2 = mid; else hi2 = mid - 1; }
+                r = lo2;
+            }
+            // one LDS atomic per (wave, round present): ballot -> leader reserves -> lanes take consecutive slots
+            unsigned dst = 0u;
+            unsigned long long todo = __ballot(r >= 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                const int r0 = __builtin_amdgcn_readlane(r, src);
+                const unsigned long long m2 = __ballot(r == r0);
+                unsigned off0 = 0u;
+                if (lane == src) off0 = atomicAdd(&rcur[r0], (unsigned)__popcll(m2));
+                off0 = (unsigned)__builtin_amdgcn_readlane((int)off0, src);
+                if (r == r0) dst = rbase[r0] + off0 + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
+                todo &= ~m2;
+            }
+            if (r >= 0) {
+                xsbuf[dst] = xb[u];
+                esbuf[dst] = (unsigned)(e0 + (long long)u * NT);
+                bsbuf[dst] = (unsigned short)b;
+            }
+        }
+    }
+    __syncthreads();
+    MDT_PROF_MARK(PH_R_PLACE);
+    // ---- 4. rounds over their own segments
+    for (int r = 0; r < nr; ++r) {
+        const int lo = rlo[r];
+        const bool oversize = rhi[r] < 0;
+        const unsigned base = rbase[r];
+        const unsigned cnt = rcur[r];
+        if (!oversize) {
+            unsigned ev[DENSE_IT], pv[DENSE_IT];
+            {
+                double xv[DENSE_IT];
+                int bv[DENSE_IT];
+#pragma unroll
+                for (int k = 0; k < DENSE_IT; ++k) {
+                    const unsigned i = (unsigned)(k * NT + tid);
+                    xv[k] = (i < cnt) ? xsbuf[base + i] : 0.0;
+                    ev[k] = (i < cnt) ? esbuf[base + i] : 0u;
+                    bv[k] = (i < cnt) ? (int)bsbuf[base + i] : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < DENSE_IT; ++k) { pv[k] = 0u; if ((unsigned)(k * NT + tid) < cnt) pv[k] = atomicAdd(&cur[bv[k]], 1u) - base; }
+#pragma unroll
+                for (int k = 0; k < DENSE_IT; ++k) { if ((unsigned)(k * NT + tid) < cnt) chunk[pv[k]] = xv[k]; }
+            }
+            __syncthreads(); // cur[b] is now the END of every bin of this round; the start is cur[b-1]
+            MDT_PROF_MARK(PH_R_PLACE);
+            unsigned res[DENSE_IT];
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                res[k] = 2u;
+                if (i < cnt) {
+                    const double v = chunk[i];
+                    const int b = bin_of_fast(v, bc, spl_t, spl_s, lut);
+                    const unsigned st = (b > 0) ? cur[b - 1] : 0u;
+                    const unsigned en = cur[b];
+                    unsigned less = st, eq;
+                    if (bin_reserved(b)) {
+                        eq = en - st;
+                    } else {
+                        eq = 0;
+                        const unsigned last = en - 1u - base;
+                        for (unsigned m2 = st - base; m2 <= last; m2 += 4u) {
+                            const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
+                            const double y0 = chunk[m2];
+                            const double y1 = chunk[i1 <= last ? i1 : last];
+                            const double y2 = chunk[i2 <= last ? i2 : last];
+                            const double y3 = chunk[i3 <= last ? i3 : last];
+                            less += (y0 < v) ? 1u : 0u;
+                            eq += (y0 == v) ? 1u : 0u;
+                            less += (i1 <= last && y1 < v) ? 1u : 0u;
+                            eq += (i1 <= last && y1 == v) ? 1u : 0u;
+                            less += (i2 <= last && y2 < v) ? 1u : 0u;
+                            eq += (i2 <= last && y2 == v) ? 1u : 0u;
+                            less += (i3 <= last && y3 < v) ? 1u : 0u;
+                            eq += (i3 <= last && y3 == v) ? 1u : 0u;
+                        }
+                    }
+                    res[k] = 2u * less + eq + 1u;
+                    for (int t = 0; t < ntgt; ++t)
+                        if (tpos[t] - less < eq) ostat[t] = v;
+                }
+            }
+            double zz[DENSE_IT];
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ztab[res[k]];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                if (i < cnt) chunk[i] = zz[k];
+            }
+            __syncthreads();
+            MDT_PROF_MARK(PH_R_COUNT);
+            // scores to time order, straight from the slots remembered in registers
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) zz[k] = ((unsigned)(k * NT + tid) < cnt) ? chunk[pv[k]] : 0.0;
+#pragma unroll
+            for (int k = 0; k < DENSE_IT; ++k) { if ((unsigned)(k * NT + tid) < cnt) zout[ev[k]] = zz[k]; }
+            __syncthreads();
+            MDT_PROF_MARK(PH_R_PLACE);
+        } else {
+            // a single bin larger than the chunk: all-equal by construction if reserved, else brute force
+            // over the members of the bin (they are contiguous in the segment)
+            const bool resv = bin_reserved(lo);
+            for (unsigned i = tid; i < cnt; i += NT) {
+                const double v = xsbuf[base + i];
+                unsigned less = base, eq = cnt;
+                if (!resv) {
+                    eq = 0;
+                    for (unsigned j2 = 0; j2 < cnt; ++j2) {
+                        const double y = xsbuf[base + j2];
+                        less += (y < v) ? 1u : 0u;
+                        eq += (y == v) ? 1u : 0u;
+                    }
+                }
+                const unsigned r2 = 2u * less + eq + 1u;
+                zout[esbuf[base + i]] = store_r2 ? (double)r2 : ztab[r2];
+                for (int t = 0; t < ntgt; ++t)
+                    if (tpos[t] - less < eq) ostat[t] = v;
+            }
+            __syncthreads();
+            if (tid == 0) cur[lo] = base + cnt; // keep the invariant "bins below the current round hold their END"
+            __syncthreads();
+        }
+    }
+    const unsigned nn = (unsigned)ints[10];
+    if (nn < (unsigned)n) { // NaNs rank last, in index order, never tied
+        for (long long e = tid; e < n; e += NT) {
+            if (binbuf[e] == BIN_NAN) {
+                unsigned less = nn;
+                for (long long i = 0; i < e; ++i) less += (binbuf[i] == BIN_NAN) ? 1u : 0u;
                 const unsigned r2 = 2u * less + 2u;
                 zout[e] = store_r2 ? (double)r2 : ztab[r2];
                 for (int t = 0; t < ntgt; ++t)
@@ -1642,6 +1935,8 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
     double* zb = kp.zbuf + (long long)blockIdx.x * kp.n_pad;
     unsigned* pbuf = kp.r2buf + (long long)blockIdx.x * kp.n_pad; // sorted-order slots (u16 or u32)
     unsigned short* bb = kp.binbuf + (long long)blockIdx.x * kp.n_pad;
+    double* xs = kp.xsbuf + (long long)blockIdx.x * kp.n_pad;
+    unsigned short* bs = kp.bsbuf + (long long)blockIdx.x * kp.n_pad;
     const bool pos16 = n < 65535;
     const double* __restrict__ ztab = kp.ztab;
     const double nan = __builtin_nan("");
@@ -1760,7 +2055,8 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
         if (need_rank_x) {
-            if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
+            if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
+            else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
         }
         MDT_PROF_MARK(PH_RANKX);
@@ -1792,7 +2088,8 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
         __syncthreads();
         const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
         auto rank_folded = [&]() {
-            if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
+            if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
+            else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, 0, kp.mode == 3);
         };
 

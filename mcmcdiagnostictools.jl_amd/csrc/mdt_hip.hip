@@ -27,6 +27,8 @@ struct mdt_ctx {
     // per-workgroup scratch
     unsigned int* r2buf = nullptr;
     double* zbuf = nullptr;
+    double* xsbuf = nullptr;
+    unsigned short* bsbuf = nullptr;
     unsigned short* binbuf = nullptr;
     long long n_pad = 0;
     // normal-score table
@@ -73,10 +75,14 @@ int ensure_scratch(mdt_ctx* ctx, long long n) {
         if (ctx->r2buf) (void)hipFree(ctx->r2buf);
         if (ctx->binbuf) (void)hipFree(ctx->binbuf);
         if (ctx->zbuf) (void)hipFree(ctx->zbuf);
-        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->n_pad = 0;
+        if (ctx->xsbuf) (void)hipFree(ctx->xsbuf);
+        if (ctx->bsbuf) (void)hipFree(ctx->bsbuf);
+        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->xsbuf = nullptr; ctx->bsbuf = nullptr; ctx->n_pad = 0;
         HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)ctx->grid * n_pad * sizeof(unsigned int)));
         HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
         HIP_TRY(hipMalloc((void**)&ctx->zbuf, (size_t)ctx->grid * n_pad * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->xsbuf, (size_t)ctx->grid * n_pad * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->bsbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
         ctx->n_pad = n_pad;
     }
     return MDT_OK;
@@ -242,6 +248,13 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     }
     kp.ztab = ctx->ztab;
     kp.r2buf = ctx->r2buf; kp.zbuf = ctx->zbuf; kp.binbuf = ctx->binbuf; kp.n_pad = ctx->n_pad;
+    kp.xsbuf = ctx->xsbuf; kp.bsbuf = ctx->bsbuf;
+    {
+        const char* rv = getenv("MDT_RANK_VARIANT");
+        // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); partitioned rounds
+        // (O(n) traffic) beyond; MDT_RANK_VARIANT forces one of them (tests, A/B timing)
+        kp.rank_variant = rv ? atoi(rv) : (n < 65535 ? 0 : 1);
+    }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
@@ -332,6 +345,8 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->r2buf) (void)hipFree(ctx->r2buf);
     if (ctx->binbuf) (void)hipFree(ctx->binbuf);
     if (ctx->zbuf) (void)hipFree(ctx->zbuf);
+    if (ctx->xsbuf) (void)hipFree(ctx->xsbuf);
+    if (ctx->bsbuf) (void)hipFree(ctx->bsbuf);
     if (ctx->ztab) (void)hipFree(ctx->ztab);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->prof) (void)hipFree(ctx->prof);

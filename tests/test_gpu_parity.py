@@ -250,3 +250,35 @@ def test_f32_other_methods_and_sizes(pkg, methods):
     inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
     assert_close(host(pkg.rhat_nested(xd, ids)), co.rhat_nested(x, inds), 1e-6)
     assert_close(host(pkg.mcse(xd)), co.mcse_mean(x), 1e-6)
+
+
+def test_config5_shape_f32_nested_and_mcse(pkg):
+    """BASELINE config 5 per-parameter shape: 10_000 draws x 16 chains (4 superchains of 4), Float32:
+    n = 160_000 exceeds the 16-bit slot range and the pooled indicator stream, so the wide paths run"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(55)
+    base = rng.standard_normal((1, 4, 3)) * 0.2
+    x = (ar1(0.6, 10_000, 16, 3, rng) + np.repeat(base, 4, axis=1)).astype(np.float32)
+    xd = dev(x)
+    ids = np.repeat(np.arange(1, 5), 4)
+    inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
+    assert_close(host(pkg.rhat_nested(xd, ids, kind="rank")), co.rhat_nested(x, inds, kind="rank"), 1e-6)
+    assert_close(host(pkg.mcse(xd)), co.mcse_mean(x), 1e-6)
+    S, R = pkg.ess_rhat(xd, kind="tail")
+    We, Wr = co.ess_rhat(x, kind="tail")
+    assert_close(host(S), We, 1e-6)
+    assert_close(host(R), Wr, 1e-6)
+
+
+def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
+    """the two rank-phase formulations (rounds re-stream the slice / partitioned rounds) give identical bits"""
+    g = load_golden("cfg1_randn_1000x4x10")
+    rng = np.random.default_rng(66)
+    x = np.concatenate([g["x"], rng.integers(1, 11, size=(1000, 4, 3)).astype(np.float64)], axis=2)
+    xd = dev(x)
+    outs = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("MDT_RANK_VARIANT", v)
+        outs[v] = [host(o) for o in pkg.bulk_tail(xd)] + [host(pkg.rank_normalize(xd, fold=True)[0])]
+    for a, b in zip(outs["0"], outs["1"]):
+        assert np.array_equal(a, b, equal_nan=True)
