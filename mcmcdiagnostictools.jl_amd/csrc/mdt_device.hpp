@@ -274,8 +274,11 @@ __device__ inline double norminv_acc(double p) {
 // normal scores by doubled rank i = 2*rank: Phi^-1((i/2 - 3/8) / (n + 1/4))  (src/utils.jl:189-193,
 // :182).  For Float32 data the quotient is rounded to Float32 before Phi^-1 and the score after.
 __global__ void ztab_kernel(double* tab, long long n, int f32) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > 2 * n) return;
+    long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 > 3 * n + 1) return;
+    // [0, 2n]: by doubled rank; [2n+1, 3n+1]: dense copy for whole ranks r = i0 - (2n+1), so that the
+    // common tie-free case reads consecutive entries instead of every other one
+    const long long i = (i0 <= 2 * n) ? i0 : 2 * (i0 - (2 * n + 1));
     double z = __builtin_nan("");
     if (i >= 2) {
         double q = ((double)i * 0.5 - 0.375) / ((double)(4 * n + 1) / 4.0);
@@ -283,7 +286,7 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
         z = norminv_acc(q);
         if (f32) z = (double)(float)z;
     }
-    tab[i] = z;
+    tab[i0] = z;
 }
 
 // ------------------------------------------------------------------ rank phase
@@ -560,7 +563,10 @@ MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* s
             }
             __syncthreads(); // cur[b] is now the END of every bin of this round; the start is cur[b-1]
             MDT_PROF_MARK(PH_R_PLACE);
-            // 3b. dense count in slot order
+            // 3b. dense count in slot order; only the order statistics that fall into this round are checked
+            int tg0 = ntgt, tg1 = 0;
+            for (int t = 0; t < ntgt; ++t)
+                if (tpos[t] - base < cnt) { tg0 = t < tg0 ? t : tg0; tg1 = t + 1; }
             unsigned res[DENSE_IT];
 #pragma unroll
             for (int k = 0; k < DENSE_IT; ++k) {
@@ -596,14 +602,14 @@ MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* s
                         }
                     }
                     res[k] = 2u * less + eq + 1u;
-                    for (int t = 0; t < ntgt; ++t)
+                    for (int t = tg0; t < tg1; ++t)
                         if (tpos[t] - less < eq) ostat[t] = v;
                 }
             }
             // normal scores by doubled rank: consecutive lanes read consecutive table entries
             double zz[DENSE_IT];
 #pragma unroll
-            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ztab[res[k]];
+            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < DENSE_IT; ++k) {
@@ -868,6 +874,9 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
             }
             __syncthreads(); // cur[b] is now the END of every bin of this round; the start is cur[b-1]
             MDT_PROF_MARK(PH_R_PLACE);
+            int tg0 = ntgt, tg1 = 0; // only the order statistics that fall into this round are checked
+            for (int t = 0; t < ntgt; ++t)
+                if (tpos[t] - base < cnt) { tg0 = t < tg0 ? t : tg0; tg1 = t + 1; }
             unsigned res[DENSE_IT];
 #pragma unroll
             for (int k = 0; k < DENSE_IT; ++k) {
@@ -901,13 +910,13 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
                         }
                     }
                     res[k] = 2u * less + eq + 1u;
-                    for (int t = 0; t < ntgt; ++t)
+                    for (int t = tg0; t < tg1; ++t)
                         if (tpos[t] - less < eq) ostat[t] = v;
                 }
             }
             double zz[DENSE_IT];
 #pragma unroll
-            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ztab[res[k]];
+            for (int k = 0; k < DENSE_IT; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < DENSE_IT; ++k) {
@@ -1378,22 +1387,37 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
         double corr = 0.0; // this lane's lag: sum over chains of the centring correction (or C_0 for lag 0)
         double bda_h = 0.0, bda_t = 0.0;
         auto finalize = [&](int j) {
+            if (w != 0) return; // wave 0 owns the lags of a block (<= 32); everything below is DPP on full waves
             const int b3 = j % 3;
             const double* pp = zpart + b3 * ZPW;
             const double* eh = zedge + b3 * 2 * SZ_EDGE;
             const double* et = eh + SZ_EDGE;
-            const long long kq = k0 + tid;
-            if (tid < 8 * G && kq < kend) {
-                double S1 = 0.0, S2 = 0.0;
-                for (int q2 = 0; q2 < NWAVE; ++q2) { S1 += pp[NWAVE * 8 + q2]; S2 += pp[NWAVE * 9 + q2]; }
-                const double mu = S1 / (double)n;
-                double head = 0.0, tail = 0.0, hsq = 0.0, tsq = 0.0;
+            const long long kq = k0 + lane;
+            // S1, S2 over the 16 wave partials
+            const double S1 = wave_sum((lane < NWAVE) ? pp[NWAVE * 8 + lane] : 0.0);
+            const double S2 = wave_sum((lane < NWAVE) ? pp[NWAVE * 9 + lane] : 0.0);
+            const double mu = S1 / (double)n;
+            // head_k = sum_{t<k} u_t, tail_k = sum of the last k values (k clamped to the kept edge):
+            // totals of the 64-wide chunks below k0, then an exclusive scan inside [k0, k0+64)
+            double ch = 0.0, ct = 0.0, chq = 0.0, ctq = 0.0;
+            const int k0c = (int)k0 < he ? (int)k0 : he;
+            for (int base = 0; base < k0c; base += 64) {
+                const int t = base + lane;
+                const double a2 = (t < k0c) ? eh[t] : 0.0, b2 = (t < k0c) ? et[he - 1 - t] : 0.0;
+                ch += wave_sum(a2);
+                ct += wave_sum(b2);
+                if (method == 2) { chq += wave_sum(a2 * a2); ctq += wave_sum(b2 * b2); }
+            }
+            const int t = (int)k0 + lane;
+            const double a2 = (t < he) ? eh[t] : 0.0, b2 = (t < he) ? et[he - 1 - t] : 0.0;
+            const double head = ch + (wave_sum_l63(a2) - a2), tail = ct + (wave_sum_l63(b2) - b2);
+            double hsq = 0.0, tsq = 0.0;
+            if (method == 2) {
+                hsq = chq + (wave_sum_l63(a2 * a2) - a2 * a2);
+                tsq = ctq + (wave_sum_l63(b2 * b2) - b2 * b2);
+            }
+            if (lane < 8 * G && kq < kend) {
                 const int kk2 = (int)kq < he ? (int)kq : he;
-                for (int t = 0; t < kk2; ++t) {
-                    const double a2 = eh[t], b2 = et[he - 1 - t];
-                    head += a2; tail += b2;
-                    hsq = fma(a2, a2, hsq); tsq = fma(b2, b2, tsq);
-                }
                 if (kq == 0) {
                     const double C = S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
                     var_j[j] = C / (double)(n - 1);

@@ -90,7 +90,7 @@ int ensure_scratch(mdt_ctx* ctx, long long n) {
 
 int ensure_ztab(mdt_ctx* ctx, long long n, int f32, hipStream_t st) {
     if (ctx->ztab_n == n && ctx->ztab_f32 == f32) return MDT_OK;
-    const long long need = 2 * n + 1;
+    const long long need = 3 * n + 2; // by doubled rank [0, 2n] + dense copy for whole ranks
     if (need > ctx->ztab_cap) {
         if (ctx->ztab) (void)hipFree(ctx->ztab);
         ctx->ztab = nullptr; ctx->ztab_cap = 0;
