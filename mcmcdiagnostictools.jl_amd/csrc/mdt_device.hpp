@@ -290,43 +290,42 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
 }
 
 // ------------------------------------------------------------------ rank phase
-// bitonic sort of one value per thread across the 1024-thread workgroup (ascending by thread id)
-__device__ inline double wg_bitonic_sort(double v, double* buf) {
-    const int tid = threadIdx.x;
-    for (int k = 2; k <= NT; k <<= 1) {
+// Sorted position (0..NT-1, unique) of one value per thread among the NT values of the workgroup.
+// Each wave sorts its 64 values with shuffles only, publishes them, and every value then counts, by
+// 15 independent binary searches, how many values of the other waves precede it (<= for earlier waves,
+// < for later ones: a stable total order).  One barrier instead of the twenty of a full bitonic network.
+__device__ inline int wg_sample_rank(double& v, double* buf) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = 2; k <= 64; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            double o;
-            if (j >= 64) {
-                buf[tid] = v;
-                __syncthreads();
-                o = buf[tid ^ j];
-                __syncthreads();
-            } else {
-                o = __shfl_xor(v, j);
-            }
-            const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+            const double o = __shfl_xor(v, j);
+            const bool up = (lane & k) == 0 || k == 64, lower = (lane & j) == 0;
             v = (lower == up) ? (o < v ? o : v) : (o > v ? o : v);
         }
     }
-    return v;
-}
-
-__device__ __forceinline__ int bin_of(double v, const double* __restrict__ t, const double* __restrict__ scale) {
-    if (v != v) return BIN_NAN;
-    if (v < t[0]) return BIN_UNDER;
-    const double top = t[K1];
-    if (v >= top) return (v == top) ? BIN_TOPEQ : BIN_OVER;
-    int lo = 0, hi = K1; // invariant: t[lo] <= v < t[hi]
+    buf[tid] = v; // ascending within each wave
+    __syncthreads();
+    int pos = lane;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int mid = (lo + hi) >> 1;
-        if (t[mid] <= v) lo = mid; else hi = mid;
+    for (int w2 = 0; w2 < NWAVE; ++w2) {
+        if (w2 == w) continue;
+        const double* run = buf + w2 * 64;
+        // number of elements of run that precede v: upper bound for earlier waves, lower bound for later ones
+        int lo = 0;
+#pragma unroll
+        for (int stp = 32; stp > 0; stp >>= 1) {
+            const double y = run[lo + stp - 1];
+            const bool before = (w2 < w) ? (y <= v) : (y < v);
+            lo += before ? stp : 0;
+        }
+        { // 64 is a power of two: the last candidate
+            const double y = run[lo < 63 ? lo : 63];
+            const bool before = (w2 < w) ? (y <= v) : (y < v);
+            lo += (lo < 64 && before) ? 1 : 0;
+        }
+        pos += lo;
     }
-    const double tk = t[lo];
-    if (v == tk) return 1 + lo * FINE;
-    double f = (v - tk) * scale[lo];
-    f = f < (double)(FINE - 2) ? f : (double)(FINE - 2);
-    return 2 + lo * FINE + (int)f;
+    return pos;
 }
 
 // Splitter search seeded by a uniform grid: cell(v) is monotone in v, and lut[cell] brackets the
@@ -450,9 +449,9 @@ MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* s
         if (es >= n) es = (long long)(tid % n);
         double v = vg(es);
         if (v != v) v = __builtin_inf();
-        v = wg_bitonic_sort(v, chunk);
-        if ((tid & 3) == 0) spl_t[tid >> 2] = v;
-        if (tid == NT - 1) spl_t[K1] = v;
+        const int spos = wg_sample_rank(v, chunk);
+        if ((spos & 3) == 0) spl_t[spos >> 2] = v;  // every 4th sample quantile is a coarse splitter
+        if (spos == NT - 1) spl_t[K1] = v;
         for (int b = tid; b < NBIN + 1; b += NT) cur[b] = 0u;
         __syncthreads();
         const double t0 = spl_t[0], top = spl_t[K1];
@@ -729,9 +728,9 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
         if (es >= n) es = (long long)(tid % n);
         double v = vg(es);
         if (v != v) v = __builtin_inf();
-        v = wg_bitonic_sort(v, chunk);
-        if ((tid & 3) == 0) spl_t[tid >> 2] = v;
-        if (tid == NT - 1) spl_t[K1] = v;
+        const int spos = wg_sample_rank(v, chunk);
+        if ((spos & 3) == 0) spl_t[spos >> 2] = v;  // every 4th sample quantile is a coarse splitter
+        if (spos == NT - 1) spl_t[K1] = v;
         for (int b = tid; b < NBIN + 1; b += NT) cur[b] = 0u;
         __syncthreads();
         const double t0 = spl_t[0], top = spl_t[K1];
