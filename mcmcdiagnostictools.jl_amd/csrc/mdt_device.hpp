@@ -101,7 +101,7 @@ struct KP {
     int ess_ok;                 // niter > 4
     int relative;
     int fold;                   // rank_normalize stage: rank |x - median| instead of x
-    int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p)
+    int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
     double ntotal;              // niter * m
@@ -128,6 +128,15 @@ struct KP {
 // phase slots of KP::prof
 enum { PH_LOAD = 0, PH_RANKX = 1, PH_SERB = 2, PH_RANKF = 3, PH_SERT = 4, PH_IND = 5, PH_OUT = 6,
        PH_R_SAMPLE = 8, PH_R_HIST = 9, PH_R_SCAN = 10, PH_R_PLACE = 11, PH_R_COUNT = 12 };
+#ifdef MDT_PROF_Q /* diagnostics build: the z-series sub-slots are lent to the two-level rank phase */
+#define MDT_PROF_QMARK(slot) MDT_PROF_MARK(slot)
+#define MDT_PROF_ZMARK(slot)
+#define MDT_PROF_QSEL(a, b) (b)
+#else
+#define MDT_PROF_QMARK(slot)
+#define MDT_PROF_ZMARK(slot) MDT_PROF_MARK(slot)
+#define MDT_PROF_QSEL(a, b) (a)
+#endif
 #define MDT_PROF_MARK(slot)                                                                   \
     do {                                                                                      \
         if (kp.prof && threadIdx.x == 0) {                                                    \
@@ -973,6 +982,397 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ rank phase, two-level (the default)
+// Level 1: the slice is partitioned by the 256 COARSE sample-quantile buckets only (one histogram of 260
+//   classes, one partition pass that appends (value, index, class) to the segment of the class's round;
+//   rounds = maximal runs of classes that fit the LDS chunk).
+// Level 2: each round re-bins ITS OWN segment with up to 8192 local fine bins (linear cut of every
+//   coarse bucket in the round, sub-bin 0 reserved for values equal to the splitter; 16-bit counters
+//   packed two per word), so a bin holds ~1-2 values whatever n is (the single-level variants degrade as
+//   n / 8196 per bin).  Bin boundaries inside the chunk are a bit mask, so the dense count needs no bin
+//   search at all; the scores go to time order straight from registers.  O(n) traffic.
+// A coarse class larger than the chunk (constant data, a huge point mass) falls back to rank_phase_p.
+constexpr int NCLS = K1 + 4;              // 0 under, 1..K1 buckets, K1+1 == top sample, K1+2 over, K1+3 NaN
+constexpr int CLS_NAN = K1 + 3;
+constexpr int NBL = 8192;                 // local fine bins per round
+constexpr int QCH = 15104;                // chunk slots of the two-level variant
+constexpr int DENSE_ITQ = (QCH + NT - 1) / NT;
+constexpr int OFF_QT = OFF_BIG;                               // double t[K1+2]
+constexpr int OFF_QIW = OFF_QT + (K1 + 2) * 8;                // double invw[K1]
+constexpr int OFF_QLUT = OFF_QIW + K1 * 8;                    // uint32 lut[GRID]
+constexpr int OFF_QCC = OFF_QLUT + GRID * 4;                  // uint32 cc[NCLS + 4]
+constexpr int OFF_QROF = OFF_QCC + (NCLS + 4) * 4;            // uint16 rof[NCLS + 4]
+constexpr int OFF_QCUR = ((OFF_QROF + (NCLS + 4) * 2 + 3) / 4) * 4; // uint32 lcur[NBL/2 + 2] (packed u16)
+constexpr int OFF_QBST = OFF_QCUR + (NBL / 2 + 2) * 4;        // uint32 bst[QCH/32 + 2]: bin starts
+constexpr int OFF_QBRS = OFF_QBST + (QCH / 32 + 2) * 4;       // uint32 brs[QCH/32 + 2]: reserved-bin starts
+constexpr int OFF_QCHUNK = ((OFF_QBRS + (QCH / 32 + 2) * 4 + 15) / 16) * 16; // double chunk[QCH]
+constexpr int LDS_RANKQ_END = OFF_QCHUNK + QCH * 8;
+static_assert(LDS_RANKQ_END <= LDS_BYTES, "two-level rank view exceeds the LDS carve");
+
+__device__ __forceinline__ int class_of(double v, const BinCtx& bc, const double* __restrict__ t,
+                                        const unsigned* __restrict__ lut) {
+    if (v != v) return CLS_NAN;
+    if (v < bc.t0) return 0;
+    if (v >= bc.top) return (v == bc.top) ? K1 + 1 : K1 + 2;
+    const unsigned lh = lut[cell_of(v, bc.t0, bc.ginv)];
+    int lo = (int)(lh & 0xFFFFu), hi = (int)(lh >> 16);
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t[mid] <= v) lo = mid; else hi = mid - 1;
+    }
+    return 1 + lo;
+}
+
+// returns false (and does nothing useful) when a coarse class does not fit the chunk
+template <class VG>
+MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
+                            unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_) {
+    const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
+    vg.make_uniform();
+    const long long n = uni(n_);
+    const int ntgt = uni(ntgt_), store_r2 = uni(store_r2_);
+    MDT_GA double* zout = uniptr_g(zout_);
+    MDT_GA unsigned* esbuf = uniptr_g(esbuf_);
+    MDT_GA unsigned short* kbuf = uniptr_g(kbuf_);
+    MDT_GA double* xsbuf = uniptr_g(xsbuf_);
+    MDT_GA unsigned short* ksbuf = uniptr_g(ksbuf_);
+    const long long step = (long long)NT * UB;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const MDT_GA double* ztab = (const MDT_GA double*)kp.ztab;
+    double* ostat = (double*)(smem + OFF_OSTAT);
+    double* scal = (double*)(smem + OFF_SCAL);
+    unsigned* tpos = (unsigned*)(smem + OFF_TPOS);
+    int* ints = (int*)(smem + OFF_INTS);
+    unsigned* wtot = (unsigned*)(smem + OFF_WTOT);
+    int* rlo = (int*)(smem + OFF_RLO);
+    int* rhi = (int*)(smem + OFF_RHI);
+    unsigned* rbase = (unsigned*)(smem + OFF_RBASE);
+    unsigned* rcur = (unsigned*)(smem + OFF_RCUR);
+    double* qt = (double*)(smem + OFF_QT);
+    double* qiw = (double*)(smem + OFF_QIW);
+    unsigned* lut = (unsigned*)(smem + OFF_QLUT);
+    unsigned* cc = (unsigned*)(smem + OFF_QCC);
+    unsigned short* rof = (unsigned short*)(smem + OFF_QROF);
+    unsigned* lcur = (unsigned*)(smem + OFF_QCUR);
+    unsigned* bst = (unsigned*)(smem + OFF_QBST);
+    unsigned* brs = (unsigned*)(smem + OFF_QBRS);
+    double* chunk = (double*)(smem + OFF_QCHUNK);
+
+    // ---- sample -> sorted positions -> coarse splitters -> grid LUT
+    {
+        const long long items = (n + NT - 1) / NT;
+        long long js = tid % items;
+        if (js * NT + tid >= n && js > 0) --js;
+        long long es = js * NT + tid;
+        if (es >= n) es = (long long)(tid % n);
+        double v = vg(es);
+        if (v != v) v = __builtin_inf();
+        const int spos = wg_sample_rank(v, chunk);
+        if ((spos & 3) == 0) qt[spos >> 2] = v;
+        if (spos == NT - 1) qt[K1] = v;
+        for (int c = tid; c < NCLS + 4; c += NT) cc[c] = 0u;
+        __syncthreads();
+        const double t0 = qt[0], top = qt[K1];
+        double ginv = (double)GRID / (top - t0);
+        if (!(ginv > 0.0) || !(ginv < __builtin_inf())) ginv = 0.0;
+        if (tid < K1) {
+            const double wd = qt[tid + 1] - qt[tid];
+            double iw = (wd > 0.0 && wd < __builtin_inf()) ? 1.0 / wd : 0.0;
+            if (!(iw < __builtin_inf())) iw = 0.0;
+            qiw[tid] = iw;
+        }
+        for (int c = tid; c < GRID; c += NT) {
+            int h[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int cc2 = c - 1 + q;
+                int lo = 0, hi = K1 - 1;
+                if (cc2 < 0) hi = 0;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    const double tm = qt[mid];
+                    const bool ok = (tm < top) ? (cell_of(tm, t0, ginv) <= cc2) : false;
+                    if (ok) lo = mid; else hi = mid - 1;
+                }
+                h[q] = lo;
+            }
+            lut[c] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        }
+        if (tid == 0) { scal[21] = t0; scal[22] = top; scal[23] = ginv; }
+        __syncthreads();
+    }
+    BinCtx bc;
+    bc.t0 = scal[21]; bc.top = scal[22]; bc.ginv = scal[23];
+    MDT_PROF_MARK(PH_R_SAMPLE);
+
+    // ---- level 1: coarse histogram (the HBM read of x)
+    for (long long e0 = tid; e0 < n; e0 += step) {
+        double xb[UB];
+        int kq[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; xb[u] = (e < n) ? vg(e) : __builtin_nan(""); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) kq[u] = class_of(xb[u], bc, qt, lut);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cc[kq[u]], 1u); }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; if (e < n) kbuf[e] = (unsigned short)kq[u]; }
+    }
+    __syncthreads();
+    MDT_PROF_MARK(PH_R_HIST);
+    // ---- class starts, rounds (maximal runs of classes that fit the chunk), class -> round
+    if (tid < 64) { // exclusive prefix over the class counts, 5 classes per lane (NCLS <= 320)
+        unsigned c5[5], tot = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int c = 5 * tid + q; c5[q] = (c < NCLS) ? cc[c] : 0u; tot += c5[q]; }
+        unsigned incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+        unsigned run = incl - tot;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { const int c = 5 * tid + q; if (c <= NCLS) cc[c] = run; run += c5[q]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned nn = cc[CLS_NAN];
+        int nr = 0, c = 0, ok = 1;
+        while (c < CLS_NAN && cc[c] < nn) {
+            if (nr >= MAXROUNDS) { atomicOr(kp.status, 1); ok = 0; break; }
+            const unsigned base = cc[c];
+            int e2 = c, hi = CLS_NAN; // last class boundary with cc[e2] - base <= QCH (cc is non-decreasing)
+            while (e2 < hi) {
+                const int mid = (e2 + hi + 1) >> 1;
+                if (cc[mid] - base <= (unsigned)QCH) e2 = mid; else hi = mid - 1;
+            }
+            if (e2 == c) { ok = 0; break; } // one class larger than the chunk
+            rbase[nr] = base; rlo[nr] = c; rhi[nr] = e2; rcur[nr] = 0u;
+            c = e2;
+            ++nr;
+        }
+        ints[0] = nr;
+        ints[10] = (int)nn;
+        ints[13] = ok;
+    }
+    __syncthreads();
+    MDT_PROF_MARK(PH_R_SCAN);
+    if (!ints[13]) { __syncthreads(); return false; }
+    const int nr = ints[0];
+    for (int c = tid; c < CLS_NAN; c += NT) { // class -> round
+        int r = 0;
+        while (r + 1 < nr && rlo[r + 1] <= c) ++r;
+        rof[c] = (unsigned short)r;
+    }
+    __syncthreads();
+    // ---- partition: append (value, index, class) to the segment of the class's round
+    for (long long e0 = tid; e0 < n; e0 += step) {
+        double xb[UB];
+        int kq[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const long long e = e0 + (long long)u * NT;
+            kq[u] = (e < n) ? (int)kbuf[e] : CLS_NAN;
+            xb[u] = (e < n) ? vg(e) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int r = (kq[u] < CLS_NAN) ? (int)rof[kq[u]] : -1;
+            unsigned dst = 0u;
+            unsigned long long todo = __ballot(r >= 0);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                const int r0 = __builtin_amdgcn_readlane(r, src);
+                const unsigned long long m2 = __ballot(r == r0);
+                unsigned off0 = 0u;
+                if (lane == src) off0 = atomicAdd(&rcur[r0], (unsigned)__popcll(m2));
+                off0 = (unsigned)__builtin_amdgcn_readlane((int)off0, src);
+                if (r == r0) dst = rbase[r0] + off0 + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
+                todo &= ~m2;
+            }
+            if (r >= 0) {
+                xsbuf[dst] = xb[u];
+                esbuf[dst] = (unsigned)(e0 + (long long)u * NT);
+                ksbuf[dst] = (unsigned short)kq[u];
+            }
+        }
+    }
+    __syncthreads();
+    MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 13));
+    // ---- level 2: rounds
+    const int tid_f = tid;
+    for (int r = 0; r < nr; ++r) {
+        // the per-slot index math (masks, LDS addresses for 15 slots) is invariant over the rounds; hoisted out
+        // of this loop it costs ~70 spilled registers, so the thread index is made opaque per round
+        int tid = tid_f;
+        asm volatile("" : "+v"(tid));
+        const int clo = rlo[r], chi = rhi[r];
+        const unsigned base = rbase[r];
+        const unsigned cnt = rcur[r];
+        int F2 = NBL / (chi - clo);
+        F2 = F2 > 4096 ? 4096 : F2;
+        const double f2m1 = (double)(F2 - 1);
+        for (int i = tid; i < NBL / 2 + 2; i += NT) lcur[i] = 0u;
+        for (int i = tid; i < QCH / 32 + 2; i += NT) { bst[i] = 0u; brs[i] = 0u; }
+        __syncthreads();
+        unsigned pv[DENSE_ITQ];
+        {
+            double xv[DENSE_ITQ];
+            int lb[DENSE_ITQ];
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                xv[k] = (i < cnt) ? xsbuf[base + i] : 0.0;
+                lb[k] = (i < cnt) ? (int)ksbuf[base + i] : clo;
+            }
+            // local fine bin: (class - clo) * F2 + sub; sub 0 = equal to the bucket's splitter (reserved)
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) {
+                const int cls = lb[k];
+                int sub = 1;
+                if (cls >= 1 && cls <= K1) {
+                    const double tk = qt[cls - 1];
+                    const double v = xv[k];
+                    if (v == tk) sub = 0;
+                    else {
+                        double f = (v - tk) * qiw[cls - 1] * f2m1;
+                        f = f < (double)(F2 - 2) ? f : (double)(F2 - 2);
+                        sub = 1 + (int)f;
+                    }
+                } else if (cls == K1 + 1) sub = 0;
+                lb[k] = (cls - clo) * F2 + sub;
+            }
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) atomicAdd(&lcur[lb[k] >> 1], 1u << ((lb[k] & 1) << 4)); }
+            __syncthreads();
+            MDT_PROF_QMARK(14);
+            // exclusive prefix over the 8192 packed 16-bit counters; mark bin starts (and reserved bins)
+            {
+                unsigned wv[4], c8[8], s8[8];
+                unsigned tot = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[q] = lcur[4 * tid + q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { c8[q] = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8[q]; }
+                unsigned incl = tot;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+                if (lane == 63) wtot[w] = incl;
+                __syncthreads();
+                unsigned woff = 0;
+                for (int q = 0; q < w; ++q) woff += wtot[q];
+                const unsigned b0 = woff + incl - tot;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lcur[4 * tid + q] = (b0 + s8[2 * q]) | ((b0 + s8[2 * q + 1]) << 16);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (c8[q]) {
+                        const unsigned st = b0 + s8[q];
+                        atomicOr(&bst[st >> 5], 1u << (st & 31));
+                        if (((8 * tid + q) % F2) == 0) atomicOr(&brs[st >> 5], 1u << (st & 31));
+                    }
+                }
+            }
+            __syncthreads();
+            MDT_PROF_QMARK(15);
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) {
+                pv[k] = 0u;
+                if ((unsigned)(k * NT + tid) < cnt) {
+                    const unsigned sh = (unsigned)(lb[k] & 1) << 4;
+                    pv[k] = (atomicAdd(&lcur[lb[k] >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) chunk[pv[k]] = xv[k]; }
+        }
+        __syncthreads();
+        MDT_PROF_MARK(PH_R_PLACE);
+        int tg0 = ntgt, tg1 = 0; // only the order statistics that fall into this round are checked
+        for (int t = 0; t < ntgt; ++t)
+            if (tpos[t] - base < cnt) { tg0 = t < tg0 ? t : tg0; tg1 = t + 1; }
+        unsigned res[DENSE_ITQ];
+        const int nwm = (int)((cnt + 31) >> 5);
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) {
+            const unsigned i = (unsigned)(k * NT + tid);
+            res[k] = 2u;
+            if (i < cnt) {
+                const double v = chunk[i];
+                // bin bounds from the start-bit mask: last start <= i, next start > i
+                int wi = (int)(i >> 5);
+                unsigned mk = bst[wi] & (0xFFFFFFFFu >> (31 - (i & 31)));
+                while (mk == 0u) mk = bst[--wi];
+                const unsigned st = ((unsigned)wi << 5) + 31u - (unsigned)__clz((int)mk);
+                int wj = (int)(i >> 5);
+                unsigned mn = ((i & 31) == 31) ? 0u : (bst[wj] & (0xFFFFFFFEu << (i & 31)));
+                while (mn == 0u && ++wj < nwm) mn = bst[wj];
+                unsigned en = mn ? ((unsigned)wj << 5) + (unsigned)(__ffs((int)mn) - 1) : cnt;
+                en = en < cnt ? en : cnt;
+                unsigned less = base + st, eq;
+                if ((brs[st >> 5] >> (st & 31)) & 1u) {
+                    eq = en - st;
+                } else {
+                    eq = 0;
+                    const unsigned last = en - 1u;
+                    for (unsigned m2 = st; m2 <= last; m2 += 4u) {
+                        const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
+                        const double y0 = chunk[m2];
+                        const double y1 = chunk[i1 <= last ? i1 : last];
+                        const double y2 = chunk[i2 <= last ? i2 : last];
+                        const double y3 = chunk[i3 <= last ? i3 : last];
+                        less += (y0 < v) ? 1u : 0u;
+                        eq += (y0 == v) ? 1u : 0u;
+                        less += (i1 <= last && y1 < v) ? 1u : 0u;
+                        eq += (i1 <= last && y1 == v) ? 1u : 0u;
+                        less += (i2 <= last && y2 < v) ? 1u : 0u;
+                        eq += (i2 <= last && y2 == v) ? 1u : 0u;
+                        less += (i3 <= last && y3 < v) ? 1u : 0u;
+                        eq += (i3 <= last && y3 == v) ? 1u : 0u;
+                    }
+                }
+                res[k] = 2u * less + eq + 1u;
+                for (int t = tg0; t < tg1; ++t)
+                    if (tpos[t] - less < eq) ostat[t] = v;
+            }
+        }
+        double zz[DENSE_ITQ];
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) {
+            const unsigned i = (unsigned)(k * NT + tid);
+            if (i < cnt) chunk[i] = zz[k];
+        }
+        __syncthreads();
+        MDT_PROF_MARK(PH_R_COUNT);
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = ((unsigned)(k * NT + tid) < cnt) ? chunk[pv[k]] : 0.0;
+        unsigned ev[DENSE_ITQ];
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) { const unsigned i = (unsigned)(k * NT + tid); ev[k] = (i < cnt) ? esbuf[base + i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) zout[ev[k]] = zz[k]; }
+        __syncthreads();
+        MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 7));
+    }
+    const unsigned nn = (unsigned)ints[10];
+    if (nn < (unsigned)n) { // NaNs rank last, in index order, never tied
+        for (long long e = tid; e < n; e += NT) {
+            if (kbuf[e] == CLS_NAN) {
+                unsigned less = nn;
+                for (long long i = 0; i < e; ++i) less += (kbuf[i] == CLS_NAN) ? 1u : 0u;
+                const unsigned r2 = 2u * less + 2u;
+                zout[e] = store_r2 ? (double)r2 : ztab[r2];
+                for (int t = 0; t < ntgt; ++t)
+                    if (tpos[t] == less) ostat[t] = __builtin_nan("");
+            }
+        }
+    }
+    if (tid == 0) ints[9] = (nn < (unsigned)n) ? 1 : 0;
+    __syncthreads();
+    return true;
+}
+
 // ------------------------------------------------------------------ series phase
 __device__ __forceinline__ long long split_row0(int k, long long niter, int rem) {
     return (long long)k * niter + (k < rem ? k : rem); // src/utils.jl:29-36
@@ -1459,9 +1859,9 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
                 if (lane == 0) { pp[NWAVE * 8 + w] = r1; pp[NWAVE * 9 + w] = r2; }
             }
             if (tid == 0) zk[b3] = Kj;
-            MDT_PROF_MARK(13); // waiting for the loads + LDS stores + moments
+            MDT_PROF_ZMARK(13); // waiting for the loads + LDS stores + moments
             __syncthreads();
-            MDT_PROF_MARK(14); // barrier
+            MDT_PROF_ZMARK(14); // barrier
             if (j + 1 < m) issue_loads(j + 1);
             {
                 // two consecutive t per lane, 16-byte LDS reads (full LDS rate): 6 reads feed 16 FMAs
@@ -1480,9 +1880,9 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
                     acc[7] = fma(a2.x, w3.y, acc[7]); acc[7] = fma(a2.y, w4.x, acc[7]);
                 }
             }
-            MDT_PROF_MARK(15); // lag products
+            MDT_PROF_ZMARK(15); // lag products
             if (j > 0) finalize(j - 1); // its S1 / S2 / edges were complete before this iteration's barrier
-            MDT_PROF_MARK(7);  // finalize
+            MDT_PROF_ZMARK(7);  // finalize
         }
         {
             double* pp = zpart; // lag partials of the whole sweep (the S1/S2 slots of buffer 0 are not touched)
@@ -2078,7 +2478,10 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
         if (need_rank_x) {
-            if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
+            if (kp.rank_variant == 2) {
+                if (!rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3))
+                    rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
+            } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
         }
@@ -2111,7 +2514,10 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
         __syncthreads();
         const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
         auto rank_folded = [&]() {
-            if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
+            if (kp.rank_variant == 2) {
+                if (!rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3))
+                    rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
+            } else if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, 0, kp.mode == 3);
         };

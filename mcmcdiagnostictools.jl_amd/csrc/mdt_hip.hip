@@ -251,9 +251,10 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.xsbuf = ctx->xsbuf; kp.bsbuf = ctx->bsbuf;
     {
         const char* rv = getenv("MDT_RANK_VARIANT");
-        // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); partitioned rounds
-        // (O(n) traffic) beyond; MDT_RANK_VARIANT forces one of them (tests, A/B timing)
-        kp.rank_variant = rv ? atoi(rv) : (n < 65535 ? 0 : 1);
+        // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); beyond, the two-level
+        // partitioned variant (O(n) traffic, bins re-cut per round; it falls back to the single-level
+        // partitioned variant 1 on a huge point mass); MDT_RANK_VARIANT forces one (tests, A/B timing)
+        kp.rank_variant = rv ? atoi(rv) : (n < 65535 ? 0 : 2);
     }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];

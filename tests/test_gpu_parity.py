@@ -235,6 +235,32 @@ def test_long_chain_shape(pkg, methods):
         pkg.ess(dev(x), kind="bulk", autocov_method=methods["fft"])
 
 
+def test_long_slices_with_point_masses_and_nans(pkg):
+    """n = 80_000 per parameter (the two-level rank phase): a constant column and a 60 % point mass force
+    its fallback, a few heavy ties and NaNs exercise the reserved bins / NaN tail; ranks bit-exact"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(77)
+    D, C = 20_000, 4
+    x = rng.standard_normal((D, C, 5))
+    x[:, :, 0] = 1.5
+    m = rng.random((D, C)) < 0.6
+    x[:, :, 1][m] = 0.0
+    x[:, :, 2] = rng.integers(0, 50, size=(D, C))
+    x[::1000, 1, 3] = np.nan
+    x[:, :, 4] = np.round(x[:, :, 4], 2)
+    xd = dev(x)
+    r, z = pkg.rank_normalize(xd)
+    for p in range(5):
+        assert np.array_equal(host(r)[:, :, p], co.tiedrank(x[:, :, p].ravel(order="F")).reshape(D, C, order="F"), equal_nan=True), p
+    xq = x[:, :, [0, 1, 2, 4]]  # (the reference throws on NaN in the tail quantile, and so do we)
+    got = [host(o) for o in pkg.bulk_tail(dev(xq))]
+    want = co.bulk_tail(xq)
+    for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+        assert_close(a, b, RTOL64, nm)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.bulk_tail(xd)
+
+
 def test_f32_other_methods_and_sizes(pkg, methods):
     from oracle import c_oracle as co
     rng = np.random.default_rng(44)
@@ -277,8 +303,9 @@ def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
     x = np.concatenate([g["x"], rng.integers(1, 11, size=(1000, 4, 3)).astype(np.float64)], axis=2)
     xd = dev(x)
     outs = {}
-    for v in ("0", "1"):
+    for v in ("0", "1", "2"):
         monkeypatch.setenv("MDT_RANK_VARIANT", v)
         outs[v] = [host(o) for o in pkg.bulk_tail(xd)] + [host(pkg.rank_normalize(xd, fold=True)[0])]
-    for a, b in zip(outs["0"], outs["1"]):
-        assert np.array_equal(a, b, equal_nan=True)
+    for v in ("1", "2"):
+        for a, b in zip(outs["0"], outs[v]):
+            assert np.array_equal(a, b, equal_nan=True), v

@@ -20,7 +20,7 @@ import torch  # noqa: E402
 import __graft_entry__ as g  # noqa: E402
 from bench import synth  # noqa: E402
 
-NAMES = {0: "load x -> registers", 1: "rank x (total)", 2: "series bulk (moments+autocov+Geyer)", 3: "rank |x-med| (total)",
+NAMES = {0: "load x -> registers", 1: "rank x (tail)", 2: "series bulk (moments+autocov+Geyer)", 3: "rank |x-med| (tail)",
          4: "series tail (moments)", 5: "indicators (tail ESS)", 6: "outputs",
          8: "  rank: sample+sort+splitters", 9: "  rank: histogram", 10: "  rank: scan+rounds", 11: "  rank: place",
          12: "  rank: count", 13: "  zseries: loads+stores", 14: "  zseries: barrier", 15: "  zseries: products+reductions",
@@ -49,7 +49,7 @@ def main():
     rc = lib.mdt_debug_phase_cycles(h, buf, 1)
     assert rc == 0, rc
     ms = ev0.elapsed_time(ev1) / a.reps
-    top = sum(buf[i] for i in range(7))  # slots 7.. are sub-phases that also advance the shared stamp
+    top = sum(buf[i] for i in range(16))  # every stamp advances the shared clock: the slots partition the time
     print(f"{a.draws}x{a.chains}x{a.params}: {ms:.3f} ms per call, {a.params / ms * 1e3:.0f} param-series/s")
     for i in sorted(NAMES):
         print(f"{NAMES[i]:42s} {100.0 * buf[i] / top:6.2f} %")
