@@ -23,15 +23,25 @@
 // Everything is deterministic (no floating-point atomics; fixed reduction trees), which the
 // reference's tests demand (test/ess_rhat.jl:167-204: results identical wherever a parameter
 // sits in the batch).
-#pragma once
+//
+// The file is included TWICE by mdt_hip.hip, into two namespaces, with two workgroup geometries:
+//   MDT_NT 1024, MDT_LDS_LIMIT 160 KiB  one workgroup per CU: long chains, big FFTs, maxlag up to 1000
+//   MDT_NT  512, MDT_LDS_LIMIT  80 KiB  TWO workgroups per CU, so that the memory-bound phases of one
+//                                       parameter overlap the LDS/VALU-bound phases of another
+// Every constant below derives from those two macros; the host picks the geometry per request.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-namespace mdt {
+#if !defined(MDT_NS) || !defined(MDT_NT) || !defined(MDT_LDS_LIMIT)
+#error "define MDT_NS, MDT_NT and MDT_LDS_LIMIT before including mdt_device.hpp"
+#endif
 
-constexpr int NT = 1024;            // threads per workgroup
-constexpr int NWAVE = NT / 64;      // 16 wave64
-constexpr int K1 = 256;             // coarse buckets (sample quantiles)
+namespace MDT_NS {
+
+constexpr int NT = MDT_NT;          // threads per workgroup
+constexpr bool SMALL = (MDT_NT == 512);
+constexpr int NWAVE = NT / 64;      // 16 or 8 wave64
+constexpr int K1 = NT / 4;          // coarse buckets (sample quantiles): every 4th of the NT sorted sample values
 constexpr int FINE = 32;            // bins per coarse bucket: 1 reserved (== splitter) + 31 linear
 constexpr int NREG = K1 * FINE;     // regular bins are 1..NREG
 constexpr int BIN_UNDER = 0;        // below the smallest sample value
@@ -39,14 +49,14 @@ constexpr int BIN_TOPEQ = NREG + 1; // equal to the largest sample value (reserv
 constexpr int BIN_OVER = NREG + 2;  // above the largest sample value
 constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless / stable sortperm)
 constexpr int NBIN = NREG + 4;
-constexpr int CH = 13760;           // elements of bin-ordered data staged in LDS per round
-constexpr int GRID = 2048;          // uniform cells over [min sample, max sample] that seed the splitter search
+constexpr int CH = SMALL ? 6400 : 13760; // elements of bin-ordered data staged in LDS per round
+constexpr int GRID = SMALL ? 1024 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
 constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
-constexpr int TL = 8192;            // series tile (elements of one split chain resident in LDS)
-constexpr int HALO = 1040;          // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
-constexpr int MAXLAG_CAP = 1000;
+constexpr int TL = SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
+constexpr int MAXLAG_CAP = SMALL ? 255 : 1000;
+constexpr int HALO = SMALL ? 296 : 1040; // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
 constexpr int MAXM = 256;           // max number of split chains chains*split_chains
-constexpr int NLAGTAB = 1024;
+constexpr int NLAGTAB = SMALL ? 256 : 1024;
 
 // ------------------------------------------------------------------ LDS carve (bytes)
 constexpr int OFF_RED = 0;                                // double red[32]
@@ -78,17 +88,20 @@ constexpr int OFF_SER = OFF_PART + NWAVE * 8 * 8;         // double ser[TL+HALO]
 constexpr int LDS_SER_END = OFF_SER + (TL + HALO) * 8;
 // indicator phase view of the big region
 constexpr int OFF_BITS = OFF_BIG;                         // uint64 bits[2][BITW]  raw ballots of one chain
-constexpr int BITW = 2048;                                // => draws <= 131072
+constexpr int BITW = SMALL ? 1024 : 2048;                 // => draws <= 65536 / 131072
 constexpr int OFF_SBITS = OFF_BITS + 2 * BITW * 8;        // uint64 sbits[2][BITW] split-aligned words
 constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
 constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})
 constexpr int OFF_IVAR = OFF_IDIF + 2 * NLAGTAB * 8;      // double imean[2][MAXM]
 constexpr int LDS_IND_END = OFF_IVAR + 2 * MAXM * 8;
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-constexpr int LDS_BYTES = cmax(LDS_RANK_END, cmax(LDS_SER_END, LDS_IND_END));
-static_assert(LDS_BYTES <= 160 * 1024, "LDS budget (160 KiB per CU on gfx950)");
+constexpr int LDS_BYTES = MDT_LDS_LIMIT; // 160 KiB per CU on gfx950: one big or two small workgroups
+static_assert(LDS_RANK_END <= LDS_BYTES && LDS_SER_END <= LDS_BYTES && LDS_IND_END <= LDS_BYTES, "LDS budget");
 
 // ------------------------------------------------------------------ kernel parameters
+} // namespace MDT_NS
+#ifndef MDT_DEVICE_COMMON
+#define MDT_DEVICE_COMMON
+namespace mdtc {
 struct KP {
     const void* x;
     long long D, C, P, n;       // draws, chains, params, n = D*C
@@ -124,6 +137,10 @@ struct KP {
     int* status;                // device status words: [0] bit0 rounds overflow, bit1 NaN hit quantile; [1] next-parameter ticket
     unsigned long long* prof;   // optional [grid*16] phase cycle counters (diagnostics), or null
 };
+} // namespace mdtc
+#endif
+namespace MDT_NS {
+using mdtc::KP;
 
 // phase slots of KP::prof
 enum { PH_LOAD = 0, PH_RANKX = 1, PH_SERB = 2, PH_RANKF = 3, PH_SERT = 4, PH_IND = 5, PH_OUT = 6,
@@ -994,8 +1011,8 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
 // A coarse class larger than the chunk (constant data, a huge point mass) falls back to rank_phase_p.
 constexpr int NCLS = K1 + 4;              // 0 under, 1..K1 buckets, K1+1 == top sample, K1+2 over, K1+3 NaN
 constexpr int CLS_NAN = K1 + 3;
-constexpr int NBL = 8192;                 // local fine bins per round
-constexpr int QCH = 15104;                // chunk slots of the two-level variant
+constexpr int NBL = NT * 8;               // local fine bins per round (8 per thread in the prefix step)
+constexpr int QCH = SMALL ? 7104 : 15104;  // chunk slots of the two-level variant
 constexpr int DENSE_ITQ = (QCH + NT - 1) / NT;
 constexpr int OFF_QT = OFF_BIG;                               // double t[K1+2]
 constexpr int OFF_QIW = OFF_QT + (K1 + 2) * 8;                // double invw[K1]
@@ -1121,7 +1138,8 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
     __syncthreads();
     MDT_PROF_MARK(PH_R_HIST);
     // ---- class starts, rounds (maximal runs of classes that fit the chunk), class -> round
-    if (tid < 64) { // exclusive prefix over the class counts, 5 classes per lane (NCLS <= 320)
+    static_assert(NCLS <= 320, "class prefix: 5 classes per lane");
+    if (tid < 64) { // exclusive prefix over the class counts, 5 classes per lane
         unsigned c5[5], tot = 0;
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const int c = 5 * tid + q; c5[q] = (c < NCLS) ? cc[c] : 0u; tot += c5[q]; }
@@ -1173,25 +1191,19 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
             kq[u] = (e < n) ? (int)kbuf[e] : CLS_NAN;
             xb[u] = (e < n) ? vg(e) : 0.0;
         }
+        // one returning LDS atomic per element on its round's cursor: lanes of a wave that share a round
+        // draw neighbouring slots, so the stores below still fill whole cache lines
+        unsigned dst[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) dst[u] = (kq[u] < CLS_NAN) ? (unsigned)rof[kq[u]] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { if (dst[u] != 0xFFFFFFFFu) dst[u] = rbase[dst[u]] + atomicAdd(&rcur[dst[u]], 1u); }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int r = (kq[u] < CLS_NAN) ? (int)rof[kq[u]] : -1;
-            unsigned dst = 0u;
-            unsigned long long todo = __ballot(r >= 0);
-            while (todo) {
-                const int src = __ffsll((long long)todo) - 1;
-                const int r0 = __builtin_amdgcn_readlane(r, src);
-                const unsigned long long m2 = __ballot(r == r0);
-                unsigned off0 = 0u;
-                if (lane == src) off0 = atomicAdd(&rcur[r0], (unsigned)__popcll(m2));
-                off0 = (unsigned)__builtin_amdgcn_readlane((int)off0, src);
-                if (r == r0) dst = rbase[r0] + off0 + (unsigned)__popcll(m2 & ((1ull << lane) - 1ull));
-                todo &= ~m2;
-            }
-            if (r >= 0) {
-                xsbuf[dst] = xb[u];
-                esbuf[dst] = (unsigned)(e0 + (long long)u * NT);
-                ksbuf[dst] = (unsigned short)kq[u];
+            if (dst[u] != 0xFFFFFFFFu) {
+                xsbuf[dst[u]] = xb[u];
+                esbuf[dst[u]] = (unsigned)(e0 + (long long)u * NT);
+                ksbuf[dst[u]] = (unsigned short)kq[u];
             }
         }
     }
@@ -1668,11 +1680,12 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
 //   ("one-pass centring"); the reference's two-pass order (src/ess_rhat.jl:529-548) is
 //   kept for raw draws in series_phase, where offsets can be large.
 constexpr int SZ = 6400;                  // doubles per buffer: niter + lag halo must fit
+constexpr int ZNBUF = SMALL ? 1 : 2;      // LDS buffers: double buffered where the LDS allows (one barrier per chain instead of two)
 constexpr int SZ_EDGE = 256;              // first / last values kept for head_k / tail_k (maxlag <= 255)
 constexpr int ZPW = NWAVE * 8 + 2 * NWAVE; // per-chain partials: 8 lags x segments, then S1 and S2 per wave
 constexpr int ZMB = 32;                   // chains per batch in the moments-only path
 constexpr int OFF_ZSER = OFF_SER;                              // double zser[2][SZ] (A / aux shared with series_phase)
-constexpr int OFF_ZPART = OFF_ZSER + 2 * SZ * 8;               // double zpart[3][ZPW]
+constexpr int OFF_ZPART = OFF_ZSER + ZNBUF * SZ * 8;           // double zpart[3][ZPW]
 constexpr int OFF_ZEDGE = OFF_ZPART + 3 * ZPW * 8;             // double zedge[3][2][SZ_EDGE]
 constexpr int OFF_ZK = OFF_ZEDGE + 3 * 2 * SZ_EDGE * 8;        // double zk[4]
 constexpr int LDS_ZSER_END = OFF_ZK + 4 * 8;
@@ -1836,7 +1849,7 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
         double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         issue_loads(0);
         for (int j = 0; j < m; ++j) {
-            double* buf = zser + (j & 1) * SZ;
+            double* buf = zser + (j % ZNBUF) * SZ;
             const int b3 = j % 3;
             double* eh = zedge + b3 * 2 * SZ_EDGE;
             double* et = eh + SZ_EDGE;
@@ -1883,6 +1896,7 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             MDT_PROF_ZMARK(15); // lag products
             if (j > 0) finalize(j - 1); // its S1 / S2 / edges were complete before this iteration's barrier
             MDT_PROF_ZMARK(7);  // finalize
+            if (ZNBUF == 1) __syncthreads(); // single buffer: the next chain overwrites what the products just read
         }
         {
             double* pp = zpart; // lag partials of the whole sweep (the S1/S2 slots of buffer 0 are not touched)
@@ -1926,7 +1940,7 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
 // natural), so no reordering pass is needed.  Pad length N = nextpow2(niter + maxlag + 1): only lags
 // <= maxlag are ever read (:482,563,590), and for those any N >= niter + maxlag + 1 gives the same
 // linear autocorrelation as the reference's nextprod([2,3], 2 niter - 1).
-constexpr int FFT_MAXN = 8192;                              // complex points resident in LDS (128 KiB)
+constexpr int FFT_MAXN = SMALL ? 4096 : 8192;               // complex points resident in LDS (64 / 128 KiB)
 constexpr int OFF_FFT = OFF_AUX;                            // double2 fbuf[FFT_MAXN]
 static_assert(OFF_FFT + FFT_MAXN * 16 <= LDS_BYTES, "FFT buffer exceeds the LDS carve");
 
@@ -2171,11 +2185,11 @@ MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, doubl
 // ------------------------------------------------------------------ indicator phase, register-resident
 // Pooled ballots straight from the registers (wave w, slot j holds elements j*NT + 64w .. +63, i.e.
 // word j*16 + w of the pooled bit stream), all split chains and both indicators in parallel.
-constexpr int IND_MAXW = 1536;   // words of the pooled stream per indicator (n <= 98304)
-constexpr int IND_CB = 16;       // split chains per batch (2 indicators x 16 chains = 32 units)
+constexpr int IND_MAXW = SMALL ? 1024 : 1536; // words of the pooled stream per indicator (n <= 65536 / 98304)
+constexpr int IND_CB = SMALL ? 8 : 16; // split chains per batch (2 indicators x 16 chains = 32 units)
 constexpr int OFF_PBITS = OFF_BIG;                           // uint64 pbits[2][IND_MAXW]
 constexpr int OFF_SB2 = OFF_PBITS + 2 * IND_MAXW * 8;        // uint64 sb2[SB2_WORDS]: units packed with stride nwS
-constexpr int SB2_WORDS = 4096;
+constexpr int SB2_WORDS = SMALL ? 2048 : 4096;
 constexpr int OFF_ITAB = OFF_SB2 + SB2_WORDS * 8;            // double itab[2][2*IND_CB][64] (cov, dif)
 constexpr int OFF_ICNT2 = OFF_ITAB + 2 * 2 * IND_CB * 64 * 8; // double icov[2][NLAGTAB], idif[2][NLAGTAB], imean[2][MAXM]
 constexpr int LDS_IND2_END = OFF_ICNT2 + (4 * NLAGTAB + 2 * MAXM) * 8;
@@ -2344,7 +2358,7 @@ __device__ __forceinline__ void store_out(void* p, long long i, double v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void mdt_kernel(const KP* __restrict__ kpp) {
     const KP& kp = *kpp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -2584,4 +2598,4 @@ __global__ __launch_bounds__(NT) void mdt_kernel(const KP* __restrict__ kpp) {
     }
 }
 
-} // namespace mdt
+} // namespace MDT_NS

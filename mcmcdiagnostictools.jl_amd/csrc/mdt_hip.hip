@@ -7,7 +7,21 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC -I include -o libmdt_hip.so mdt_hip.hip
 // -ffp-contract=off: the scalar formulas that mirror Julia expressions (quantile, median,
 // var+, tau) must round like Julia does; hot loops use explicit fma().
+// the device code, once per workgroup geometry (see the head of mdt_device.hpp)
+#define MDT_NS mdt_big
+#define MDT_NT 1024
+#define MDT_LDS_LIMIT (160 * 1024)
 #include "mdt_device.hpp"
+#undef MDT_NS
+#undef MDT_NT
+#undef MDT_LDS_LIMIT
+#define MDT_NS mdt_small
+#define MDT_NT 512
+#define MDT_LDS_LIMIT (80 * 1024)
+#include "mdt_device.hpp"
+#undef MDT_NS
+#undef MDT_NT
+#undef MDT_LDS_LIMIT
 #include "mdt_hip.h"
 
 #include <cmath>
@@ -17,12 +31,13 @@
 #include <new>
 #include <string>
 
-using namespace mdt;
+using mdtc::KP;
 
 struct mdt_ctx {
     int device = 0;
     int num_cu = 0;
-    int grid = 0;
+    int grid = 0;      // workgroups the scratch is sized for: 2 per CU (the small geometry)
+    int force_cfg = 0; // MDT_CONFIG=big|small (tests, A/B timing): 1 big, 2 small, 0 automatic
     std::string err;
     // per-workgroup scratch
     unsigned int* r2buf = nullptr;
@@ -99,7 +114,7 @@ int ensure_ztab(mdt_ctx* ctx, long long n, int f32, hipStream_t st) {
     }
     const int bs = 256;
     const long long nb = (need + bs - 1) / bs;
-    hipLaunchKernelGGL(ztab_kernel, dim3((unsigned)nb), dim3(bs), 0, st, ctx->ztab, n, f32);
+    hipLaunchKernelGGL(mdt_big::ztab_kernel, dim3((unsigned)nb), dim3(bs), 0, st, ctx->ztab, n, f32);
     HIP_TRY(hipGetLastError());
     ctx->ztab_n = n;
     ctx->ztab_f32 = f32;
@@ -142,13 +157,20 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     }
     if (!(a->tail_prob > 0.0 && a->tail_prob < 1.0) && rq.need_et) return fail(ctx, MDT_EARG, "tail_prob must be in (0, 1)");
     // engine limits
-    if (m > MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
-    if (maxlag > MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
+    static_assert(mdt_big::MAXM == mdt_small::MAXM, "one limit for both geometries");
+    if (m > mdt_big::MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
+    if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
-    if (rq.need_et && D > (long long)BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
-    if (a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok && niter + maxlag + 1 > FFT_MAXN)
+    if (rq.need_et && D > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
+    const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
+    if (fft && niter + maxlag + 1 > mdt_big::FFT_MAXN)
         return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod on the device needs draws/split_chains + maxlag + 1 <= 8192 "
                                            "(the in-LDS transform); use AutocovMethod for longer chains");
+    // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
+    // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
+    const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
+                            D <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
+    const bool small = ctx->force_cfg == 2 ? small_fits : (ctx->force_cfg == 1 ? false : small_fits);
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)a->stream;
@@ -254,7 +276,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); beyond, the two-level
         // partitioned variant (O(n) traffic, bins re-cut per round; it falls back to the single-level
         // partitioned variant 1 on a huge point mass); MDT_RANK_VARIANT forces one (tests, A/B timing)
-        kp.rank_variant = rv ? atoi(rv) : (n < 65535 ? 0 : 2);
+        kp.rank_variant = rv ? atoi(rv) : ((small || n >= 65535) ? 2 : 0);
     }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
@@ -263,14 +285,17 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.status = ctx->status;
     kp.prof = ctx->prof;
 
-    const unsigned grid = (unsigned)((P < ctx->grid) ? P : ctx->grid);
-    void (*kern)(const KP*) = f32 ? mdt_kernel<float> : mdt_kernel<double>;
+    const long long wgs = small ? ctx->grid : ctx->grid / 2;
+    const unsigned grid = (unsigned)((P < wgs) ? P : wgs);
+    void (*kern)(const KP*) = small ? (f32 ? mdt_small::mdt_kernel<float> : mdt_small::mdt_kernel<double>)
+                                    : (f32 ? mdt_big::mdt_kernel<float> : mdt_big::mdt_kernel<double>);
     // the parameter block travels through a small ring in device memory: the kernel reads it with
     // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
     KP* slot = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
     if (ctx->kp_next % KP_RING == 0) HIP_TRY(hipStreamSynchronize(st)); // never overwrite a slot still in flight
     HIP_TRY(hipMemcpyAsync(slot, &kp, sizeof(KP), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), LDS_BYTES, st, (const KP*)slot);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(small ? mdt_small::NT : mdt_big::NT), small ? mdt_small::LDS_BYTES : mdt_big::LDS_BYTES, st,
+                       (const KP*)slot);
     HIP_TRY(hipGetLastError());
 
     if (a->location == MDT_HOST) {
@@ -310,13 +335,16 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
     ctx->num_cu = prop.multiProcessorCount;
-    ctx->grid = ctx->num_cu > 0 ? ctx->num_cu : 256; // one 1024-thread workgroup per CU (LDS-bound)
-    if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = v; } // diagnostics
+    ctx->grid = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256); // two 512-thread or one 1024-thread workgroup per CU (LDS-bound)
+    if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = 2 * v; } // diagnostics: workgroups of the big geometry
+    if (const char* c = getenv("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : 0);
     if (hipMalloc((void**)&ctx->status, 2 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
     // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
-    const void* kerns[] = {(const void*)mdt_kernel<double>, (const void*)mdt_kernel<float>};
-    for (const void* k : kerns) {
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+    const void* kerns[] = {(const void*)mdt_big::mdt_kernel<double>, (const void*)mdt_big::mdt_kernel<float>,
+                           (const void*)mdt_small::mdt_kernel<double>, (const void*)mdt_small::mdt_kernel<float>};
+    for (int ki = 0; ki < 4; ++ki) {
+        const void* k = kerns[ki];
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, ki < 2 ? mdt_big::LDS_BYTES : mdt_small::LDS_BYTES) != hipSuccess) {
             (void)hipFree(ctx->status);
             delete ctx;
             return MDT_ERUNTIME;
