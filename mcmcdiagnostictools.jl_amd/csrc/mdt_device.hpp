@@ -226,6 +226,9 @@ struct SerZ {          // series = normal scores, already in time order in the p
 
 
 // ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ long long split_row0(int k, long long niter, int rem) {
+    return (long long)k * niter + (k < rem ? k : rem); // src/utils.jl:29-36
+}
 __device__ __forceinline__ double jl_min(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a < b ? a : b); }
 __device__ __forceinline__ double jl_max(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : (a > b ? a : b); }
 
@@ -260,6 +263,45 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// 64-bit integer wave sum on the same DPP tree (total in every lane)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_add_i64(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xF, true);
+    return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    v = dpp_add_i64<0x111, 0xF>(v);
+    v = dpp_add_i64<0x112, 0xF>(v);
+    v = dpp_add_i64<0x114, 0xF>(v);
+    v = dpp_add_i64<0x118, 0xF>(v);
+    v = dpp_add_i64<0x142, 0xA>(v);
+    v = dpp_add_i64<0x143, 0xC>(v);
+    const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// Fixed-point images of a shifted normal score u (|u| < 32) and of its square (< 256): adding the magic
+// 1.5 * 2^6 (resp. 1.5 * 2^9) leaves u in units of 2^-46 (u^2: 2^-43) in the mantissa.  Sums of up to 2^13
+// such integers are exact in int64 and do not depend on the order of summation: the moments of the
+// z-series are the same bits whatever the geometry, the input order (time / segments) or the reduction
+// tree.  Longer chains coarsen the unit by one bit per doubling (Fx::make), still ~1e-12 of a unit score.
+struct Fx {
+    double m1, m2;   // magic addends for u and u^2
+    double i1, i2;   // value of one integer unit
+    __device__ static Fx make(long long nterms) {
+        int extra = 0;
+        while ((8192LL << extra) < nterms) ++extra;
+        Fx f;
+        f.m1 = ldexp(96.0, extra);
+        f.m2 = ldexp(768.0, extra);
+        f.i1 = ldexp(1.0, extra - 46);
+        f.i2 = ldexp(1.0, extra - 43);
+        return f;
+    }
+    __device__ __forceinline__ long long u(double x) const { return __double_as_longlong(x + m1) - __double_as_longlong(m1); }
+    __device__ __forceinline__ long long uu(double x) const { return __double_as_longlong(x + m2) - __double_as_longlong(m2); }
+};
+
 // deterministic workgroup sum; every thread returns the same value
 __device__ __forceinline__ double wg_sum(double v, double* red) {
     v = wave_sum(v);
@@ -1040,10 +1082,53 @@ __device__ __forceinline__ int class_of(double v, const BinCtx& bc, const double
     return 1 + lo;
 }
 
-// returns false (and does nothing useful) when a coarse class does not fit the chunk
+// Partition-time view of the region above the class tables: one tile of (value, index, class) records
+// that is counting-sorted by (round [, split chain]) in LDS, so that every run leaves for global memory
+// as a contiguous, fully coalesced stream.  The (split chain x class) counters of the histogram pass
+// live in the same bytes before the first tile arrives.
+constexpr int PT = 8;                                          // elements per thread per tile
+constexpr int TILE = NT * PT;
+constexpr int SEGKEYS = 128;                                   // (round, split chain) keys of a segmented output
+constexpr int KMAX = 256;                                      // partition keys (>= MAXROUNDS, >= SEGKEYS)
+static_assert(KMAX >= MAXROUNDS && KMAX >= SEGKEYS && KMAX <= NT, "partition key tables");
+constexpr int OFF_TSEG = OFF_QCUR;                             // uint32 segcur[KMAX]: global cursor of every key (round-major)
+constexpr int OFF_TSEG2 = OFF_TSEG + KMAX * 4;                 // uint32 segcur2[KMAX]: the same in chain-major order
+constexpr int OFF_TCNT = OFF_TSEG2 + KMAX * 4;                 // uint32 kcnt[KMAX]: count / placement cursor of the tile
+constexpr int OFF_TOFF = OFF_TCNT + KMAX * 4;                  // uint32 koff[KMAX]: start of the key's run inside the tile
+constexpr int OFF_TGB = OFF_TOFF + KMAX * 4;                   // uint32 kg[KMAX]: global destination of the key's run
+constexpr int OFF_TGB2 = OFF_TGB + KMAX * 4;                   // uint32 kg2[KMAX]: chain-major destination of the key's run
+constexpr int OFF_TX = ((OFF_TGB2 + KMAX * 4 + 15) / 16) * 16; // double tx[TILE]
+constexpr int OFF_TE = OFF_TX + TILE * 8;                      // uint32 te[TILE]
+constexpr int OFF_TK = OFF_TE + TILE * 4;                      // uint16 tk[TILE]
+constexpr int OFF_CC2 = OFF_TX;                                // uint32 cc2[NJ][NCLS] (histogram pass only)
+static_assert(OFF_TK + TILE * 2 <= LDS_BYTES, "partition tile exceeds the LDS carve");
+static_assert(64 * NCLS * 4 <= TILE * 14, "class x chain counters must fit the tile bytes");
+// element tag (kbuf / ksbuf, 16 bits): class (9 bits) | split-chain slot (6 bits) << 9 | first-row flag << 15
+constexpr int TAG_CLS = 511;
+
+// Split chain of element e of the pooled slice (src/utils.jl:29-36: split k takes rows k*niter + min(k, rem)
+// onward, niter of them; one row is dropped after each of the first `rem` splits): slot in [0, m), or m for a
+// dropped row; first = the row opens its split chain.
+__device__ __forceinline__ unsigned split_slot(unsigned e, unsigned D, unsigned niter, unsigned rem, unsigned s, unsigned m, bool& first) {
+    const unsigned c = e / D, row = e - c * D;
+    const unsigned b = rem * (niter + 1u);
+    unsigned kk, off;
+    if (row < b) { kk = row / (niter + 1u); off = row - kk * (niter + 1u); }
+    else { const unsigned q = (row - b) / niter; kk = rem + q; off = row - b - q * niter; }
+    first = off == 0u;
+    return (off >= niter) ? m : c * s + kk;
+}
+
+// Returns 0 when it cannot serve the slice (a coarse class larger than the chunk, or NaNs together with a
+// segmented request): the caller falls back to rank_phase_p.  1: scores (or doubled ranks) are in zout in
+// TIME order.  2: (only when seg_req) scores are in zout in CHAIN-MAJOR SEGMENT order: split chain j owns
+// zout[j * niter, (j + 1) * niter), filled round by round (each (round, chain) segment is one contiguous,
+// coalesced stream); the draw index inside the chain of every slot is in esbuf, read as 16-bit words, in the
+// same order (written by the partition pass); the score of the first draw of every split chain is in
+// mean_j[] -- series_z_phase<true> scatters that to time order in LDS: no scattered global access anywhere.
 template <class VG>
-MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
-                            unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_) {
+MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
+                           unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_, int seg_req_) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     vg.make_uniform();
     const long long n = uni(n_);
@@ -1065,6 +1150,12 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
     int* rhi = (int*)(smem + OFF_RHI);
     unsigned* rbase = (unsigned*)(smem + OFF_RBASE);
     unsigned* rcur = (unsigned*)(smem + OFF_RCUR);
+    double* mean_j = (double*)(smem + OFF_MEAN);
+    unsigned* segsave = (unsigned*)(smem + OFF_VAR);     // [SEGKEYS + 1] starts of the (round, slot) segments
+    unsigned* e0tab = segsave + SEGKEYS + 4;             // [65] pooled index of the first draw of slot j
+    unsigned* cumj = e0tab + 68;                         // [65] draws of slot j placed by the earlier rounds
+    int* adj2 = (int*)(cumj + 68);                       // [65] this round: slot of a round member + adj2[j] = its place in chain-major order
+    static_assert((SEGKEYS + 4 + 3 * 68) * 4 <= MAXM * 8, "segment tables must fit the var_j bytes");
     double* qt = (double*)(smem + OFF_QT);
     double* qiw = (double*)(smem + OFF_QIW);
     unsigned* lut = (unsigned*)(smem + OFF_QLUT);
@@ -1074,6 +1165,20 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
     unsigned* bst = (unsigned*)(smem + OFF_QBST);
     unsigned* brs = (unsigned*)(smem + OFF_QBRS);
     double* chunk = (double*)(smem + OFF_QCHUNK);
+    unsigned* cc2 = (unsigned*)(smem + OFF_CC2);
+    unsigned* segcur = (unsigned*)(smem + OFF_TSEG);
+    unsigned* kcnt = (unsigned*)(smem + OFF_TCNT);
+    unsigned* koff = (unsigned*)(smem + OFF_TOFF);
+    unsigned* kg = (unsigned*)(smem + OFF_TGB);
+    unsigned* segcur2 = (unsigned*)(smem + OFF_TSEG2);
+    unsigned* kg2 = (unsigned*)(smem + OFF_TGB2);
+    MDT_GA unsigned short* locbuf = (MDT_GA unsigned short*)esbuf; // segmented output: draw index of every member, chain-major
+    double* tx = (double*)(smem + OFF_TX);
+    unsigned* te = (unsigned*)(smem + OFF_TE);
+    unsigned short* tk = (unsigned short*)(smem + OFF_TK);
+    const unsigned uD = (unsigned)kp.D, uniter = (unsigned)kp.niter, urem = (unsigned)kp.rem, us = (unsigned)kp.s, um = (unsigned)kp.m;
+    // split-chain slots per class in the histogram: m real ones + 1 for dropped rows
+    const int NJ = (uni(seg_req_) && kp.m + 1 <= 64) ? kp.m + 1 : 1;
 
     // ---- sample -> sorted positions -> coarse splitters -> grid LUT
     {
@@ -1084,11 +1189,11 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
         if (es >= n) es = (long long)(tid % n);
         double v = vg(es);
         if (v != v) v = __builtin_inf();
-        const int spos = wg_sample_rank(v, chunk);
+        const int spos = wg_sample_rank(v, tx);
         if ((spos & 3) == 0) qt[spos >> 2] = v;
         if (spos == NT - 1) qt[K1] = v;
-        for (int c = tid; c < NCLS + 4; c += NT) cc[c] = 0u;
         __syncthreads();
+        for (int c = tid; c < NJ * NCLS; c += NT) cc2[c] = 0u; // (aliases the sample buffer: after the barrier)
         const double t0 = qt[0], top = qt[K1];
         double ginv = (double)GRID / (top - t0);
         if (!(ginv > 0.0) || !(ginv < __builtin_inf())) ginv = 0.0;
@@ -1102,13 +1207,13 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
             int h[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int cc2 = c - 1 + q;
+                const int cq = c - 1 + q;
                 int lo = 0, hi = K1 - 1;
-                if (cc2 < 0) hi = 0;
+                if (cq < 0) hi = 0;
                 while (lo < hi) {
                     const int mid = (lo + hi + 1) >> 1;
                     const double tm = qt[mid];
-                    const bool ok = (tm < top) ? (cell_of(tm, t0, ginv) <= cc2) : false;
+                    const bool ok = (tm < top) ? (cell_of(tm, t0, ginv) <= cq) : false;
                     if (ok) lo = mid; else hi = mid - 1;
                 }
                 h[q] = lo;
@@ -1122,22 +1227,35 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
     bc.t0 = scal[21]; bc.top = scal[22]; bc.ginv = scal[23];
     MDT_PROF_MARK(PH_R_SAMPLE);
 
-    // ---- level 1: coarse histogram (the HBM read of x)
+    // ---- level 1: coarse histogram per (split-chain slot, class): the HBM read of x
     for (long long e0 = tid; e0 < n; e0 += step) {
         double xb[UB];
-        int kq[UB];
+        unsigned kq[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; xb[u] = (e < n) ? vg(e) : __builtin_nan(""); }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) kq[u] = class_of(xb[u], bc, qt, lut);
+        for (int u = 0; u < UB; ++u) {
+            kq[u] = (unsigned)class_of(xb[u], bc, qt, lut);
+            if (NJ > 1) {
+                bool first;
+                const unsigned j = split_slot((unsigned)(e0 + (long long)u * NT), uD, uniter, urem, us, um, first);
+                kq[u] |= (j << 9) | (first ? 0x8000u : 0u);
+            }
+        }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cc[kq[u]], 1u); }
+        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cc2[(kq[u] >> 9 & 63u) * NCLS + (kq[u] & TAG_CLS)], 1u); }
 #pragma unroll
         for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; if (e < n) kbuf[e] = (unsigned short)kq[u]; }
     }
     __syncthreads();
     MDT_PROF_MARK(PH_R_HIST);
-    // ---- class starts, rounds (maximal runs of classes that fit the chunk), class -> round
+    // ---- class totals -> class starts, rounds (maximal runs of classes that fit the chunk), class -> round
+    for (int c = tid; c < NCLS + 4; c += NT) {
+        unsigned t = 0;
+        if (c < NCLS) for (int j = 0; j < NJ; ++j) t += cc2[j * NCLS + c];
+        cc[c] = t;
+    }
+    __syncthreads();
     static_assert(NCLS <= 320, "class prefix: 5 classes per lane");
     if (tid < 64) { // exclusive prefix over the class counts, 5 classes per lane
         unsigned c5[5], tot = 0;
@@ -1163,51 +1281,146 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
                 if (cc[mid] - base <= (unsigned)QCH) e2 = mid; else hi = mid - 1;
             }
             if (e2 == c) { ok = 0; break; } // one class larger than the chunk
-            rbase[nr] = base; rlo[nr] = c; rhi[nr] = e2; rcur[nr] = 0u;
+            rbase[nr] = base; rlo[nr] = c; rhi[nr] = e2; rcur[nr] = cc[e2] - base;
             c = e2;
             ++nr;
         }
+        const int segout = NJ > 1 && nr * NJ <= SEGKEYS && kp.niter <= 65535;
+        if (NJ > 1 && nn < (unsigned)n) ok = 0; // NaNs and a segmented request: the single-level variant serves it
         ints[0] = nr;
         ints[10] = (int)nn;
         ints[13] = ok;
+        ints[15] = segout ? NJ : 1;
     }
     __syncthreads();
     MDT_PROF_MARK(PH_R_SCAN);
-    if (!ints[13]) { __syncthreads(); return false; }
+    if (!ints[13]) { __syncthreads(); return 0; }
     const int nr = ints[0];
+    const int NJe = ints[15];         // split-chain slots per round in the partition keys (1: rounds only)
+    const bool segout = NJe > 1;
+    const int NKEY = nr * NJe;
     for (int c = tid; c < CLS_NAN; c += NT) { // class -> round
         int r = 0;
         while (r + 1 < nr && rlo[r + 1] <= c) ++r;
         rof[c] = (unsigned short)r;
     }
-    __syncthreads();
-    // ---- partition: append (value, index, class) to the segment of the class's round
-    for (long long e0 = tid; e0 < n; e0 += step) {
-        double xb[UB];
-        int kq[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const long long e = e0 + (long long)u * NT;
-            kq[u] = (e < n) ? (int)kbuf[e] : CLS_NAN;
-            xb[u] = (e < n) ? vg(e) : 0.0;
+    // ---- key (= round * NJe + slot) sizes -> global segment starts
+    {
+        unsigned cnt = 0;
+        if (tid < NKEY) {
+            const int r = tid / NJe, j = tid - r * NJe;
+            if (segout) { for (int c = rlo[r]; c < rhi[r]; ++c) cnt += cc2[j * NCLS + c]; }
+            else cnt = rcur[r];
         }
-        // one returning LDS atomic per element on its round's cursor: lanes of a wave that share a round
-        // draw neighbouring slots, so the stores below still fill whole cache lines
-        unsigned dst[UB];
+        unsigned incl = cnt;
 #pragma unroll
-        for (int u = 0; u < UB; ++u) dst[u] = (kq[u] < CLS_NAN) ? (unsigned)rof[kq[u]] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int u = 0; u < UB; ++u) { if (dst[u] != 0xFFFFFFFFu) dst[u] = rbase[dst[u]] + atomicAdd(&rcur[dst[u]], 1u); }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            if (dst[u] != 0xFFFFFFFFu) {
-                xsbuf[dst[u]] = xb[u];
-                esbuf[dst[u]] = (unsigned)(e0 + (long long)u * NT);
-                ksbuf[dst[u]] = (unsigned short)kq[u];
-            }
+        for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads(); // (also: every read of cc2 is done before the tile area is reused)
+        unsigned woff = 0;
+        for (int q = 0; q < w; ++q) woff += wtot[q];
+        const unsigned start = woff + incl - cnt;
+        if (tid < KMAX) { segcur[tid] = start; kcnt[tid] = 0u; }
+        if (segout && tid <= NKEY) segsave[tid] = (tid < NKEY) ? start : (unsigned)n;
+        if (segout && tid <= (int)um) {
+            const unsigned c = (unsigned)tid / us, kk = (unsigned)tid - c * us;
+            e0tab[tid] = (tid < (int)um) ? c * uD + (unsigned)split_row0((int)kk, kp.niter, kp.rem) : 0u;
+            cumj[tid] = 0u;
         }
     }
     __syncthreads();
+    if (segout && tid < NKEY) { // chain-major start of segment (r, j): j * niter + members of j in the earlier rounds
+        const int r = tid / NJe, j = tid - r * NJe;
+        unsigned cum = 0;
+        for (int r2 = 0; r2 < r; ++r2) cum += segsave[r2 * NJe + j + 1] - segsave[r2 * NJe + j];
+        segcur2[tid] = (unsigned)j * uniter + cum;
+    }
+    __syncthreads();
+    // ---- partition, tile by tile: count keys, prefix, place in LDS, stream every run out
+    {
+        double xv[PT];
+        unsigned kv[PT];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const long long e = (long long)u * NT + tid;
+            kv[u] = (e < n) ? (unsigned)kbuf[e] : (unsigned)CLS_NAN;
+            xv[u] = (e < n) ? vg(e) : 0.0;
+        }
+        for (long long tile0 = 0; tile0 < n; tile0 += TILE) {
+            unsigned key[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const unsigned cls = kv[u] & TAG_CLS;
+                key[u] = (cls < (unsigned)CLS_NAN) ? (unsigned)rof[cls] * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < PT; ++u) { if (key[u] != 0xFFFFFFFFu) atomicAdd(&kcnt[key[u]], 1u); }
+            double xn[PT]; // the next tile is in flight while this one is sorted
+            unsigned kn[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const long long e = tile0 + TILE + (long long)u * NT + tid;
+                kn[u] = (e < n) ? (unsigned)kbuf[e] : (unsigned)CLS_NAN;
+                xn[u] = (e < n) ? vg(e) : 0.0;
+            }
+            __syncthreads();
+            {
+                const unsigned c = (tid < NKEY) ? kcnt[tid] : 0u;
+                unsigned incl = c;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+                unsigned woff = 0;
+                if (NKEY > 64) {
+                    if (lane == 63) wtot[w] = incl;
+                    __syncthreads();
+                    for (int q = 0; q < w; ++q) woff += wtot[q];
+                }
+                if (tid < NKEY) {
+                    koff[tid] = woff + incl - c;
+                    const unsigned g = segcur[tid];
+                    kg[tid] = g;
+                    segcur[tid] = g + c;
+                    if (segout) { const unsigned g2 = segcur2[tid]; kg2[tid] = g2; segcur2[tid] = g2 + c; }
+                    kcnt[tid] = 0u;
+                }
+            }
+            __syncthreads();
+            unsigned slot[PT];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) { slot[u] = 0u; if (key[u] != 0xFFFFFFFFu) slot[u] = koff[key[u]] + atomicAdd(&kcnt[key[u]], 1u); }
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                if (key[u] != 0xFFFFFFFFu) {
+                    tx[slot[u]] = xv[u];
+                    const unsigned e = (unsigned)(tile0 + (long long)u * NT + tid);
+                    te[slot[u]] = segout ? e - e0tab[kv[u] >> 9 & 63u] : e; // segmented: draw index inside the split chain
+                    tk[slot[u]] = (unsigned short)kv[u];
+                }
+            }
+            __syncthreads();
+            for (int k = w; k < NKEY; k += NWAVE) {
+                const unsigned cnt = kcnt[k], o = koff[k], g = kg[k];
+                if (segout) {
+                    const unsigned g2 = kg2[k];
+                    for (unsigned i = lane; i < cnt; i += 64u) {
+                        xsbuf[g + i] = tx[o + i];
+                        locbuf[g2 + i] = (unsigned short)te[o + i];
+                        ksbuf[g + i] = tk[o + i];
+                    }
+                } else {
+                    for (unsigned i = lane; i < cnt; i += 64u) {
+                        xsbuf[g + i] = tx[o + i];
+                        esbuf[g + i] = te[o + i];
+                        ksbuf[g + i] = tk[o + i];
+                    }
+                }
+                if (lane == 0) kcnt[k] = 0u;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PT; ++u) { xv[u] = xn[u]; kv[u] = kn[u]; }
+        }
+    }
     MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 13));
     // ---- level 2: rounds
     const int tid_f = tid;
@@ -1224,8 +1437,17 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
         const double f2m1 = (double)(F2 - 1);
         for (int i = tid; i < NBL / 2 + 2; i += NT) lcur[i] = 0u;
         for (int i = tid; i < QCH / 32 + 2; i += NT) { bst[i] = 0u; brs[i] = 0u; }
+        if (segout && tid < NJe) {
+            const unsigned st = segsave[r * NJe + tid], c = segsave[r * NJe + tid + 1] - st, done = cumj[tid];
+            adj2[tid] = (int)((unsigned)tid * uniter + done) - (int)(st - base);
+            cumj[tid] = done + c;
+        }
         __syncthreads();
         unsigned pv[DENSE_ITQ];
+        unsigned fmask = 0u; // slots of this thread that hold the first draw of a split chain
+        unsigned jpk[(DENSE_ITQ + 3) / 4]; // split-chain slot of every member, 8 bits each
+#pragma unroll
+        for (int k = 0; k < (DENSE_ITQ + 3) / 4; ++k) jpk[k] = 0u;
         {
             double xv[DENSE_ITQ];
             int lb[DENSE_ITQ];
@@ -1238,14 +1460,16 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
             // local fine bin: (class - clo) * F2 + sub; sub 0 = equal to the bucket's splitter (reserved)
 #pragma unroll
             for (int k = 0; k < DENSE_ITQ; ++k) {
-                const int cls = lb[k];
+                fmask |= ((unsigned)lb[k] >> 15 & 1u) << k;
+                jpk[k >> 2] |= ((unsigned)lb[k] >> 9 & 63u) << ((k & 3) << 3);
+                const int cls = lb[k] & TAG_CLS;
                 int sub = 1;
                 if (cls >= 1 && cls <= K1) {
-                    const double tk = qt[cls - 1];
+                    const double tk2 = qt[cls - 1];
                     const double v = xv[k];
-                    if (v == tk) sub = 0;
+                    if (v == tk2) sub = 0;
                     else {
-                        double f = (v - tk) * qiw[cls - 1] * f2m1;
+                        double f = (v - tk2) * qiw[cls - 1] * f2m1;
                         f = f < (double)(F2 - 2) ? f : (double)(F2 - 2);
                         sub = 1 + (int)f;
                     }
@@ -1256,7 +1480,7 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
             for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) atomicAdd(&lcur[lb[k] >> 1], 1u << ((lb[k] & 1) << 4)); }
             __syncthreads();
             MDT_PROF_QMARK(14);
-            // exclusive prefix over the 8192 packed 16-bit counters; mark bin starts (and reserved bins)
+            // exclusive prefix over the packed 16-bit counters; mark bin starts (and reserved bins)
             {
                 unsigned wv[4], c8[8], s8[8];
                 unsigned tot = 0;
@@ -1346,33 +1570,47 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
                     if (tpos[t] - less < eq) ostat[t] = v;
             }
         }
-        double zz[DENSE_ITQ];
+        {
+            double zz[DENSE_ITQ];
 #pragma unroll
-        for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
-        __syncthreads();
+            for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
+            __syncthreads();
 #pragma unroll
-        for (int k = 0; k < DENSE_ITQ; ++k) {
-            const unsigned i = (unsigned)(k * NT + tid);
-            if (i < cnt) chunk[i] = zz[k];
+            for (int k = 0; k < DENSE_ITQ; ++k) {
+                const unsigned i = (unsigned)(k * NT + tid);
+                if (i < cnt) chunk[i] = zz[k];
+            }
+            __syncthreads();
+            MDT_PROF_MARK(PH_R_COUNT);
+#pragma unroll
+            for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = ((unsigned)(k * NT + tid) < cnt) ? chunk[pv[k]] : 0.0;
+            if (segout) {
+                // chain-major segment order: every (round, chain) segment is one coalesced stream; the first
+                // draw of every split chain leaves its score in mean_j[] (the shift K_j of series_z_phase)
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) {
+                    const unsigned i = (unsigned)(k * NT + tid);
+                    const unsigned j = jpk[k >> 2] >> ((k & 3) << 3) & 63u;
+                    if (i < cnt) zout[(int)i + adj2[j]] = zz[k];
+                    if ((fmask >> k & 1u) && j < um) mean_j[j] = zz[k];
+                }
+            } else {
+                unsigned ev[DENSE_ITQ];
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) { const unsigned i = (unsigned)(k * NT + tid); ev[k] = (i < cnt) ? esbuf[base + i] : 0u; }
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) zout[ev[k]] = zz[k]; }
+            }
         }
-        __syncthreads();
-        MDT_PROF_MARK(PH_R_COUNT);
-#pragma unroll
-        for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = ((unsigned)(k * NT + tid) < cnt) ? chunk[pv[k]] : 0.0;
-        unsigned ev[DENSE_ITQ];
-#pragma unroll
-        for (int k = 0; k < DENSE_ITQ; ++k) { const unsigned i = (unsigned)(k * NT + tid); ev[k] = (i < cnt) ? esbuf[base + i] : 0u; }
-#pragma unroll
-        for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) zout[ev[k]] = zz[k]; }
         __syncthreads();
         MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 7));
     }
     const unsigned nn = (unsigned)ints[10];
-    if (nn < (unsigned)n) { // NaNs rank last, in index order, never tied
+    if (nn < (unsigned)n) { // NaNs rank last, in index order, never tied (time-order output only, see above)
         for (long long e = tid; e < n; e += NT) {
-            if (kbuf[e] == CLS_NAN) {
+            if ((kbuf[e] & TAG_CLS) == CLS_NAN) {
                 unsigned less = nn;
-                for (long long i = 0; i < e; ++i) less += (kbuf[i] == CLS_NAN) ? 1u : 0u;
+                for (long long i = 0; i < e; ++i) less += ((kbuf[i] & TAG_CLS) == CLS_NAN) ? 1u : 0u;
                 const unsigned r2 = 2u * less + 2u;
                 zout[e] = store_r2 ? (double)r2 : ztab[r2];
                 for (int t = 0; t < ntgt; ++t)
@@ -1380,15 +1618,12 @@ MDT_PHASE bool rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* s
             }
         }
     }
-    if (tid == 0) ints[9] = (nn < (unsigned)n) ? 1 : 0;
+    if (tid == 0) { ints[9] = (nn < (unsigned)n) ? 1 : 0; ints[14] = nr; }
     __syncthreads();
-    return true;
+    return segout ? 2 : 1;
 }
 
 // ------------------------------------------------------------------ series phase
-__device__ __forceinline__ long long split_row0(int k, long long niter, int rem) {
-    return (long long)k * niter + (k < rem ? k : rem); // src/utils.jl:29-36
-}
 
 // Accumulate sum_t ser[t]*ser[t+kb+i], i < NL, over this wave's t-segment of [0, tlen).
 // Waves are arranged as G lag groups x (NWAVE/G) t-segments.
@@ -1497,11 +1732,13 @@ __device__ inline void series_combine(const KPT& kp, unsigned char* smem, int bl
 
 // Y(c, row) -> value of the series for original chain c at draw `row`.
 // Leaves mean_j / var_j of every split chain in LDS; returns rhat (and ess if want_acov).
+// have_moments: mean_j / var_j are already in LDS (the z-series moments sweep, series_z_phase) and are
+// used as they are -- the means centre the lag products, nothing overwrites them.
 template <class YF>
-MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned char* smem) {
+MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned char* smem, bool have_moments_ = false) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     Y.make_uniform();
-    const bool want_acov = uni(want_acov_);
+    const bool want_acov = uni(want_acov_), have_moments = uni(have_moments_);
     const int tid = threadIdx.x;
     double* red = (double*)(smem + OFF_RED);
     double* scal = (double*)(smem + OFF_SCAL);
@@ -1542,7 +1779,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
             const int c = j / s, kk = j % s;
             const long long r0 = split_row0(kk, niter, kp.rem);
             double mu;
-            if (block == 0) {
+            if (block == 0 && !have_moments) {
                 // pass 1: mean of the split chain (Statistics.mean!, src/ess_rhat.jl:529)
                 double sum = 0.0;
                 for (int ti = 0; ti < ntile; ++ti) {
@@ -1581,7 +1818,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
             for (int ti = 0; ti < ntile; ++ti) {
                 const long long tau = (long long)ti * TL;
                 const int tlen = (int)((niter - tau < TL) ? niter - tau : TL);
-                if (ntile == 1 && block == 0) {
+                if (ntile == 1 && block == 0 && !have_moments) {
                     for (int i = tid; i < tlen + halo; i += NT) {
                         const double cv = (i < tlen) ? ser[i] - mu : 0.0;
                         ser[i] = cv;
@@ -1645,7 +1882,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
                     for (int q2 = 0; q2 < nseg; ++q2) sm += part[tid * nseg + q2];
                     if (kq == 0) {
                         sm = S2;
-                        var_j[j] = sm / (double)(niter - 1); // Statistics.var(...; mean, corrected=true)
+                        if (!have_moments) var_j[j] = sm / (double)(niter - 1); // Statistics.var(...; mean, corrected=true)
                     }
                     A[kq] += sm;
                 }
@@ -1667,14 +1904,18 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
 
 // ------------------------------------------------------------------ series phase for normal scores
 // The hot variant of series_phase for the rank-normalised series (values bounded, |z| < 9).
-// Moments: every thread sums u = z - K_j and u^2 over the values it loads (K_j = mean of 8 draws
-// spread over the chain: exactly 0 deviation for a constant chain), reduced per wave with DPP and
-// across waves in a fixed order.  This is the ONLY place means and variances come from, so
-// rhat(x) and ess_rhat(x).rhat are bit-identical, as in the reference (test/ess_rhat.jl:167-204).
-//   moments only (R-hat): no LDS staging, no per-chain barrier at all;
-//   with autocovariance: one split chain per LDS buffer, double buffered -> ONE barrier per split
-//   chain, the loads of chain j+1 in flight while chain j is processed; lagged products of the
-//   shifted values are centred algebraically:
+// Input, SEG = false: z in time order (per-workgroup scratch).  SEG = true: z in chain-major SEGMENT order
+//   as rank_phase_q leaves it (split chain j owns z[j * niter ..), members in ranking-round order, the draw
+//   index of every slot beside it, 16 bits): a chain is streamed -- coalesced -- and scattered to time order
+//   in LDS, so the ranking never issues a scattered global store.
+// Moments: u = z - K_j with K_j = the score of the chain's first draw (exactly 0 deviation for a constant
+//   chain); S1 = sum u, S2 = sum u^2 are accumulated in FIXED POINT (struct Fx): exact integer sums, so
+//   they do not depend on the order of the terms.  This is the ONLY place the means and variances of a
+//   z-series come from, so rhat(x) and ess_rhat(x).rhat are bit-identical, as in the reference
+//   (test/ess_rhat.jl:167-204), whatever the geometry, the input order or the autocovariance path.
+//   want_acov = false streams the chains once (any length), no LDS staging, no per-chain barrier.
+// Autocovariance: one split chain per LDS buffer, the loads of chain j+1 in flight while chain j is
+//   processed; lagged products of the shifted values are centred algebraically:
 //     sum_t (u_t - mu)(u_{t+k} - mu) = P_k - mu (S1 - tail_k + S1 - head_k) + (n - k) mu^2,
 //   head_k / tail_k = sums of the first / last k values.  With |mu| << sd this loses nothing
 //   ("one-pass centring"); the reference's two-pass order (src/ess_rhat.jl:529-548) is
@@ -1682,20 +1923,23 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
 constexpr int SZ = 6400;                  // doubles per buffer: niter + lag halo must fit
 constexpr int ZNBUF = SMALL ? 1 : 2;      // LDS buffers: double buffered where the LDS allows (one barrier per chain instead of two)
 constexpr int SZ_EDGE = 256;              // first / last values kept for head_k / tail_k (maxlag <= 255)
-constexpr int ZPW = NWAVE * 8 + 2 * NWAVE; // per-chain partials: 8 lags x segments, then S1 and S2 per wave
-constexpr int ZMB = 32;                   // chains per batch in the moments-only path
-constexpr int OFF_ZSER = OFF_SER;                              // double zser[2][SZ] (A / aux shared with series_phase)
+constexpr int LD = (SZ + NT - 1) / NT;    // values per thread
+constexpr int ZPW = NWAVE * 8 + 2 * NWAVE; // per-chain partials: 8 lags x segments, then S1 and S2 (int64) per wave
+constexpr int OFF_ZS1 = OFF_LAGA;                              // moments-only view: int64 S1i[MAXM], S2i[MAXM], double Kt[MAXM]
+static_assert(3 * MAXM * 8 <= 3 * NLAGTAB * 8, "moments-only view must fit the lag tables");
+constexpr int OFF_ZSER = OFF_SER;                              // double zser[ZNBUF][SZ] (A / aux shared with series_phase)
 constexpr int OFF_ZPART = OFF_ZSER + ZNBUF * SZ * 8;           // double zpart[3][ZPW]
 constexpr int OFF_ZEDGE = OFF_ZPART + 3 * ZPW * 8;             // double zedge[3][2][SZ_EDGE]
 constexpr int OFF_ZK = OFF_ZEDGE + 3 * 2 * SZ_EDGE * 8;        // double zk[4]
 constexpr int LDS_ZSER_END = OFF_ZK + 4 * 8;
-constexpr int OFF_ZMOM = OFF_SER;                              // moments-only view: double zmom[ZMB][NWAVE][2], zkk[ZMB]
 static_assert(LDS_ZSER_END <= LDS_BYTES, "z-series view exceeds the LDS carve");
 
-MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_acov_, unsigned char* smem) {
+template <bool SEG>
+MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsigned short* loc_, bool want_acov_, unsigned char* smem) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     const bool want_acov = uni(want_acov_);
     const MDT_GA double* z = uniptr_g(z_);
+    const MDT_GA unsigned short* locs = uniptr_g(loc_);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* scal = (double*)(smem + OFF_SCAL);
     int* ints = (int*)(smem + OFF_INTS);
@@ -1712,60 +1956,64 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
     const int m = kp.m, s = kp.s, rem = kp.rem;
     const long long maxlag = kp.maxlag;
     const int method = kp.method;
-    constexpr int LD = (SZ + NT - 1) / NT; // values per thread
     const int he = n < SZ_EDGE ? n : SZ_EDGE;
     SeriesOut out;
 
-    double v[LD];
-    double Kj = 0.0;
-    auto issue_loads = [&](int j) {
+    const Fx fx = Fx::make(niter);
+    auto chain_e0 = [&](int j) -> long long {
         const int c = j / s, kk = j - c * s;
-        const MDT_GA double* zc = z + (long long)c * D + split_row0(kk, niter, rem);
-#pragma unroll
-        for (int u = 0; u < LD; ++u) {
-            const int i = u * NT + tid;
-            v[u] = (i < n) ? zc[i] : 0.0;
-        }
-        double ks = 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) ks += zc[((long long)u * n) >> 3];
-        Kj = ks * 0.125;
+        return (long long)c * D + split_row0(kk, niter, rem);
     };
-    // this thread's share of S1 = sum u, S2 = sum u^2 (u = z - K_j), then the wave totals
-    auto wave_moments = [&](double& r1, double& r2) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int u = 0; u < LD; ++u) {
-            const int i = u * NT + tid;
-            if (i < n) { const double uu = v[u] - Kj; s1 += uu; s2 = fma(uu, uu, s2); }
-        }
-        r1 = wave_sum(s1);
-        r2 = wave_sum(s2);
+    auto chain_K = [&](int j) -> double {
+        if (SEG) return mean_j[j];
+        // (a vector load on purpose: the scalar cache is not coherent with the stores of the rank phase)
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        return z[chain_e0(j) + zero];
     };
 
     if (!want_acov) {
-        // ---- moments only: registers -> DPP -> one barrier per batch of chains
-        double* zmom = (double*)(smem + OFF_ZMOM);
-        double* zkk = zmom + ZMB * NWAVE * 2;
-        for (int jb = 0; jb < m; jb += ZMB) {
-            const int nb = (m - jb < ZMB) ? m - jb : ZMB;
-            for (int jl = 0; jl < nb; ++jl) {
-                issue_loads(jb + jl);
-                double r1, r2;
-                wave_moments(r1, r2);
-                if (lane == 0) { zmom[(jl * NWAVE + w) * 2] = r1; zmom[(jl * NWAVE + w) * 2 + 1] = r2; }
-                if (tid == 0) zkk[jl] = Kj;
+        // ---- moments only: stream every chain once, integer sums, one LDS atomic per wave and chain
+        long long* S1i = (long long*)(smem + OFF_ZS1);
+        long long* S2i = S1i + MAXM;
+        double* Kt = (double*)(S2i + MAXM);
+        for (int k = tid; k < 2 * MAXM; k += NT) S1i[k] = 0;
+        __syncthreads();
+        constexpr int SU = 8; // loads in flight per thread
+        for (int j = 0; j < m; ++j) {
+            const double Kj = chain_K(j);
+            const MDT_GA double* zc = z + (SEG ? (long long)j * niter : chain_e0(j));
+            long long a1 = 0, a2 = 0;
+            for (int i0 = 0; i0 < n; i0 += NT * SU) {
+                double vv[SU];
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const int i = i0 + u * NT + tid;
+                    vv[u] = (i < n) ? zc[i] : Kj;
+                }
+#pragma unroll
+                for (int u = 0; u < SU; ++u) {
+                    const double uu = vv[u] - Kj; // exactly 0 for the padding lanes
+                    a1 += fx.u(uu);
+                    a2 += fx.uu(uu * uu);
+                }
             }
-            __syncthreads();
-            if (tid < nb) {
-                double S1 = 0.0, S2 = 0.0;
-                for (int q = 0; q < NWAVE; ++q) { S1 += zmom[(tid * NWAVE + q) * 2]; S2 += zmom[(tid * NWAVE + q) * 2 + 1]; }
-                const double mu = S1 / (double)n;
-                mean_j[jb + tid] = zkk[tid] + mu;
-                var_j[jb + tid] = (S2 - mu * S1) / (double)(n - 1);
+            a1 = wave_sum_i64(a1);
+            a2 = wave_sum_i64(a2);
+            if (lane == 0) {
+                atomicAdd((unsigned long long*)&S1i[j], (unsigned long long)a1);
+                atomicAdd((unsigned long long*)&S2i[j], (unsigned long long)a2);
             }
-            __syncthreads();
+            if (tid == 0) Kt[j] = Kj;
         }
+        __syncthreads();
+        for (int j = tid; j < m; j += NT) {
+            const double S1 = (double)S1i[j] * fx.i1, S2 = (double)S2i[j] * fx.i2;
+            const double mu = S1 / (double)n;
+            var_j[j] = (S2 - mu * S1) / (double)(n - 1);
+            mean_j[j] = Kt[j] + mu;
+        }
+        __syncthreads();
         if (tid == 0) series_combine(kp, smem, 0, 1, false);
         __syncthreads();
         out.rhat = scal[2];
@@ -1774,6 +2022,31 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
         return out;
     }
 
+    double v[LD];
+    int loc[LD];
+    double Kj = 0.0;
+    auto issue_loads = [&](int j) {
+        if (SEG) {
+            const MDT_GA double* zc = z + (long long)j * niter;
+            const MDT_GA unsigned short* lc = locs + (long long)j * niter;
+#pragma unroll
+            for (int u = 0; u < LD; ++u) {
+                const int i = u * NT + tid;
+                v[u] = (i < n) ? zc[i] : 0.0;
+                loc[u] = (i < n) ? (int)lc[i] : i;
+            }
+        } else {
+            const MDT_GA double* zc = z + chain_e0(j);
+#pragma unroll
+            for (int u = 0; u < LD; ++u) {
+                const int i = u * NT + tid;
+                v[u] = (i < n) ? zc[i] : 0.0;
+                loc[u] = i;
+            }
+        }
+        Kj = chain_K(j);
+    };
+
     for (int k = tid; k < NLAGTAB; k += NT) { A[k] = 0.0; aux[k] = 0.0; aux[NLAGTAB + k] = 0.0; }
     if (tid == 0) { ints[1] = 0; ints[2] = 0; }
     __syncthreads();
@@ -1781,7 +2054,7 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
     long long k0 = 0;
     int block = 0;
     while (true) {
-        const int G = 4;                 // 32 lags per block: lag-groups of 8 x 4 time-segments
+        const int G = 4;                 // 32 lags per block: lag-groups of 8 x NWAVE/4 time-segments
         long long kend = k0 + 32;
         if (kend > maxlag + 1) kend = maxlag + 1;
         const int nseg = NWAVE / G;
@@ -1802,12 +2075,13 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             if (w != 0) return; // wave 0 owns the lags of a block (<= 32); everything below is DPP on full waves
             const int b3 = j % 3;
             const double* pp = zpart + b3 * ZPW;
+            const long long* ppi = (const long long*)pp;
             const double* eh = zedge + b3 * 2 * SZ_EDGE;
             const double* et = eh + SZ_EDGE;
             const long long kq = k0 + lane;
-            // S1, S2 over the 16 wave partials
-            const double S1 = wave_sum((lane < NWAVE) ? pp[NWAVE * 8 + lane] : 0.0);
-            const double S2 = wave_sum((lane < NWAVE) ? pp[NWAVE * 9 + lane] : 0.0);
+            // S1, S2: exact integer sums of the wave partials
+            const double S1 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 8 + lane] : 0) * fx.i1;
+            const double S2 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 9 + lane] : 0) * fx.i2;
             const double mu = S1 / (double)n;
             // head_k = sum_{t<k} u_t, tail_k = sum of the last k values (k clamped to the kept edge):
             // totals of the 64-wide chunks below k0, then an exclusive scan inside [k0, k0+64)
@@ -1854,23 +2128,27 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             double* eh = zedge + b3 * 2 * SZ_EDGE;
             double* et = eh + SZ_EDGE;
             double* pp = zpart + b3 * ZPW;
+            // the chain, shifted by K_j, to time order (SEG: scattered here, in LDS, not in global memory),
+            // its first / last values, and this thread's share of the integer moments
+            long long a1 = 0, a2 = 0;
 #pragma unroll
             for (int u = 0; u < LD; ++u) {
                 const int i = u * NT + tid;
-                const double uu = v[u] - Kj;
                 if (i < n) {
-                    buf[i] = uu;
-                    if (i < he) eh[i] = uu;
-                    if (i >= n - he) et[i - (n - he)] = uu;
+                    const double uu = v[u] - Kj;
+                    const int l = loc[u];
+                    buf[l] = uu;
+                    if (l < he) eh[l] = uu;
+                    if (l >= n - he) et[l - (n - he)] = uu;
+                    a1 += fx.u(uu);
+                    a2 += fx.uu(uu * uu);
                 } else if (i < n + halo) {
                     buf[i] = 0.0;
                 }
             }
-            {
-                double r1, r2;
-                wave_moments(r1, r2);
-                if (lane == 0) { pp[NWAVE * 8 + w] = r1; pp[NWAVE * 9 + w] = r2; }
-            }
+            a1 = wave_sum_i64(a1);
+            a2 = wave_sum_i64(a2);
+            if (lane == 0) { ((long long*)pp)[NWAVE * 8 + w] = a1; ((long long*)pp)[NWAVE * 9 + w] = a2; }
             if (tid == 0) zk[b3] = Kj;
             MDT_PROF_ZMARK(13); // waiting for the loads + LDS stores + moments
             __syncthreads();
@@ -1896,7 +2174,7 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, bool want_ac
             MDT_PROF_ZMARK(15); // lag products
             if (j > 0) finalize(j - 1); // its S1 / S2 / edges were complete before this iteration's barrier
             MDT_PROF_ZMARK(7);  // finalize
-            if (ZNBUF == 1) __syncthreads(); // single buffer: the next chain overwrites what the products just read
+            if (ZNBUF == 1) __syncthreads(); // single buffer: the next chain overwrites what was just read
         }
         {
             double* pp = zpart; // lag partials of the whole sweep (the S1/S2 slots of buffer 0 are not touched)
@@ -2491,10 +2769,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __syncthreads();
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
+        // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
+        const bool seg_req = zfast && kp.method != 1 && kp.mode != 3;
+        int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
-                if (!rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3))
-                    rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
+                rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3, seg_req && (kp.need_eb || kp.need_rb));
+                if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
@@ -2528,9 +2809,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         __syncthreads();
         const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
         auto rank_folded = [&]() {
+            rk = 0;
             if (kp.rank_variant == 2) {
-                if (!rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3))
-                    rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
+                rk = rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3, seg_req);
+                if (!rk) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, 0, kp.mode == 3);
@@ -2551,11 +2833,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (kp.need_eb || kp.need_rb) {
             const bool acov = kp.need_eb && kp.ess_ok;
             SeriesOut so;
+            // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
+            // bits whichever autocovariance path follows
             if (acov && kp.method == 1) {
-                (void)(zfast ? series_z_phase(kp, zb, false, smem) : series_phase(kp, YZ, false, smem));
+                (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_fft_phase(kp, YZ, smem);
+            } else if (zfast || !acov) {
+                so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, acov, smem) : series_z_phase<false>(kp, zb, nullptr, acov, smem);
             } else {
-                so = zfast ? series_z_phase(kp, zb, acov, smem) : series_phase(kp, YZ, acov, smem);
+                (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
+                so = series_phase(kp, YZ, true, smem, true);
             }
             rb = (kp.mode == 1) ? 0.0 : so.rhat;
             if (acov) eb = so.ess;
@@ -2570,7 +2857,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (kp.need_rt) {
             rank_folded();
             MDT_PROF_MARK(PH_RANKF);
-            const SeriesOut so = zfast ? series_z_phase(kp, zb, false, smem) : series_phase(kp, YZ, false, smem);
+            const SeriesOut so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, false, smem) : series_z_phase<false>(kp, zb, nullptr, false, smem);
             rt = so.rhat;
             if (kp.mode == 1) {
                 if (tid == 0) scal[20] = nested_combine();
