@@ -198,6 +198,8 @@ struct SrcPlain {      // x itself
     const MDT_GA T* xp;
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); }
     __device__ __forceinline__ double operator()(long long e) const { return (double)xp[e]; }
+    // element base + i with a wave-uniform base: scalar base register + 32-bit lane offset, no 64-bit address math
+    __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)(xp + base)[i]; }
 };
 template <typename T>
 struct SrcFold {       // |x - median|, evaluated in T like the reference (src/utils.jl:155)
@@ -206,6 +208,10 @@ struct SrcFold {       // |x - median|, evaluated in T like the reference (src/u
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); med = uni(med); }
     __device__ __forceinline__ double operator()(long long e) const {
         const T d = (T)(xp[e] - med);
+        return (double)(d < (T)0 ? -d : d);
+    }
+    __device__ __forceinline__ double at(long long base, unsigned i) const {
+        const T d = (T)((xp + base)[i] - med);
         return (double)(d < (T)0 ? -d : d);
     }
 };
@@ -223,6 +229,9 @@ struct SerZ {          // series = normal scores, already in time order in the p
     __device__ __forceinline__ double operator()(int c, long long row) const { return z[(long long)c * D + row]; }
 };
 #define MDT_PHASE __device__ __attribute__((noinline))
+// Keeps a loaded value "used" so that the compiler cannot sink the load under the condition of a later
+// select (it then branches around every single LDS read and waits for each one separately).
+__device__ __forceinline__ unsigned keep(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 
 // ------------------------------------------------------------------ small helpers
@@ -263,6 +272,20 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// inclusive prefix sum over the 64 lanes with DPP only (no LDS permute, no lane-index registers)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_add_u32(unsigned v) {
+    return v + (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ unsigned wave_incl_scan_u32(unsigned v) {
+    v = dpp_add_u32<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add_u32<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add_u32<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add_u32<0x118, 0xF>(v); // row_shr:8 -> inclusive inside every row of 16
+    v = dpp_add_u32<0x142, 0xA>(v); // row_bcast:15: rows 1 and 3 take the total of the row before
+    v = dpp_add_u32<0x143, 0xC>(v); // row_bcast:31: rows 2 and 3 take the total of the first half
+    return v;
+}
 // 64-bit integer wave sum on the same DPP tree (total in every lane)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ long long dpp_add_i64(long long v) {
@@ -301,6 +324,11 @@ struct Fx {
     __device__ __forceinline__ long long u(double x) const { return __double_as_longlong(x + m1) - __double_as_longlong(m1); }
     __device__ __forceinline__ long long uu(double x) const { return __double_as_longlong(x + m2) - __double_as_longlong(m2); }
 };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding GLOBAL
+// load and store (s_waitcnt vmcnt(0)): a prefetch issued before it is serialised and every streamed store
+// is waited for.  Use where the data exchanged across the barrier lives in LDS.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // deterministic workgroup sum; every thread returns the same value
 __device__ __forceinline__ double wg_sum(double v, double* red) {
@@ -442,12 +470,7 @@ __device__ inline void wg_exscan_bins(unsigned* cur, unsigned* wtot, unsigned to
         loc[i] = s;
         s += c;
     }
-    unsigned incl = s;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned u = __shfl_up(incl, o);
-        if (lane >= o) incl += u;
-    }
+    const unsigned incl = wave_incl_scan_u32(s);
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
     unsigned woff = 0;
@@ -1092,16 +1115,17 @@ constexpr int SEGKEYS = 128;                                   // (round, split 
 constexpr int KMAX = 256;                                      // partition keys (>= MAXROUNDS, >= SEGKEYS)
 static_assert(KMAX >= MAXROUNDS && KMAX >= SEGKEYS && KMAX <= NT, "partition key tables");
 constexpr int OFF_TSEG = OFF_QCUR;                             // uint32 segcur[KMAX]: global cursor of every key (round-major)
+constexpr int KDUMMY = KMAX;                                   // key of a slot past the end of the slice (never read back)
 constexpr int OFF_TSEG2 = OFF_TSEG + KMAX * 4;                 // uint32 segcur2[KMAX]: the same in chain-major order
-constexpr int OFF_TCNT = OFF_TSEG2 + KMAX * 4;                 // uint32 kcnt[KMAX]: count / placement cursor of the tile
-constexpr int OFF_TOFF = OFF_TCNT + KMAX * 4;                  // uint32 koff[KMAX]: start of the key's run inside the tile
-constexpr int OFF_TGB = OFF_TOFF + KMAX * 4;                   // uint32 kg[KMAX]: global destination of the key's run
+constexpr int OFF_TCNT = OFF_TSEG2 + KMAX * 4;                 // uint32 kcnt[KMAX+4]: count / placement cursor of the tile
+constexpr int OFF_TOFF = OFF_TCNT + (KMAX + 4) * 4;            // uint32 koff[KMAX+4]: start of the key's run inside the tile
+constexpr int OFF_TGB = OFF_TOFF + (KMAX + 4) * 4;             // uint32 kg[KMAX]: global destination of the key's run
 constexpr int OFF_TGB2 = OFF_TGB + KMAX * 4;                   // uint32 kg2[KMAX]: chain-major destination of the key's run
-constexpr int OFF_TX = ((OFF_TGB2 + KMAX * 4 + 15) / 16) * 16; // double tx[TILE]
-constexpr int OFF_TE = OFF_TX + TILE * 8;                      // uint32 te[TILE]
-constexpr int OFF_TK = OFF_TE + TILE * 4;                      // uint16 tk[TILE]
+constexpr int OFF_TX = ((OFF_TGB2 + KMAX * 4 + 15) / 16) * 16; // double tx[TILE+2]  (+ a dump record for dummy keys)
+constexpr int OFF_TE = OFF_TX + (TILE + 2) * 8;                // uint32 te[TILE+2]
+constexpr int OFF_TK = OFF_TE + (TILE + 2) * 4;                // uint16 tk[TILE+2]
 constexpr int OFF_CC2 = OFF_TX;                                // uint32 cc2[NJ][NCLS] (histogram pass only)
-static_assert(OFF_TK + TILE * 2 <= LDS_BYTES, "partition tile exceeds the LDS carve");
+static_assert(OFF_TK + (TILE + 2) * 2 <= LDS_BYTES, "partition tile exceeds the LDS carve");
 static_assert(64 * NCLS * 4 <= TILE * 14, "class x chain counters must fit the tile bytes");
 // element tag (kbuf / ksbuf, 16 bits): class (9 bits) | split-chain slot (6 bits) << 9 | first-row flag << 15
 constexpr int TAG_CLS = 511;
@@ -1261,9 +1285,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         unsigned c5[5], tot = 0;
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const int c = 5 * tid + q; c5[q] = (c < NCLS) ? cc[c] : 0u; tot += c5[q]; }
-        unsigned incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+        const unsigned incl = wave_incl_scan_u32(tot);
         unsigned run = incl - tot;
 #pragma unroll
         for (int q = 0; q < 5; ++q) { const int c = 5 * tid + q; if (c <= NCLS) cc[c] = run; run += c5[q]; }
@@ -1312,9 +1334,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             if (segout) { for (int c = rlo[r]; c < rhi[r]; ++c) cnt += cc2[j * NCLS + c]; }
             else cnt = rcur[r];
         }
-        unsigned incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+        const unsigned incl = wave_incl_scan_u32(cnt);
         if (lane == 63) wtot[w] = incl;
         __syncthreads(); // (also: every read of cc2 is done before the tile area is reused)
         unsigned woff = 0;
@@ -1322,9 +1342,9 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         const unsigned start = woff + incl - cnt;
         if (tid < KMAX) { segcur[tid] = start; kcnt[tid] = 0u; }
         if (segout && tid <= NKEY) segsave[tid] = (tid < NKEY) ? start : (unsigned)n;
-        if (segout && tid <= (int)um) {
+        if (tid < 68) {
             const unsigned c = (unsigned)tid / us, kk = (unsigned)tid - c * us;
-            e0tab[tid] = (tid < (int)um) ? c * uD + (unsigned)split_row0((int)kk, kp.niter, kp.rem) : 0u;
+            e0tab[tid] = (segout && tid < (int)um) ? c * uD + (unsigned)split_row0((int)kk, kp.niter, kp.rem) : 0u;
             cumj[tid] = 0u;
         }
     }
@@ -1336,43 +1356,63 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         segcur2[tid] = (unsigned)j * uniter + cum;
     }
     __syncthreads();
-    // ---- partition, tile by tile: count keys, prefix, place in LDS, stream every run out
+    // ---- partition, tile by tile: count keys, prefix, place in LDS, stream every run out.
+    // Straight-line code: slots past the end of the slice (last tile) and NaNs carry the dummy key, their
+    // record lands in a dump slot; every LDS access of the 8 elements of a thread is issued back to back.
     {
+        if (tid == 0) { kcnt[KDUMMY] = 0u; koff[KDUMMY] = (unsigned)TILE; }
         double xv[PT];
         unsigned kv[PT];
+        const unsigned nlast = (unsigned)(n - 1);
 #pragma unroll
         for (int u = 0; u < PT; ++u) {
-            const long long e = (long long)u * NT + tid;
-            kv[u] = (e < n) ? (unsigned)kbuf[e] : (unsigned)CLS_NAN;
-            xv[u] = (e < n) ? vg(e) : 0.0;
+            unsigned i = (unsigned)(u * NT + tid);
+            i = i < nlast ? i : nlast;
+            kv[u] = (unsigned)kbuf[i];
+            xv[u] = vg.at(0, i);
         }
+        wg_barrier_lds();
         for (long long tile0 = 0; tile0 < n; tile0 += TILE) {
-            unsigned key[PT];
+            const unsigned left = (unsigned)((n - tile0 < TILE) ? n - tile0 : TILE); // valid slots of this tile
+            unsigned key[PT]; // key | class tag << 16
 #pragma unroll
             for (int u = 0; u < PT; ++u) {
                 const unsigned cls = kv[u] & TAG_CLS;
-                key[u] = (cls < (unsigned)CLS_NAN) ? (unsigned)rof[cls] * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : 0xFFFFFFFFu;
+                const bool ok = (unsigned)(u * NT + tid) < left && cls < (unsigned)CLS_NAN;
+                const unsigned r = keep((unsigned)rof[ok ? cls : 0u]);
+                key[u] = (ok ? r * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : (unsigned)KDUMMY) | (kv[u] << 16);
             }
 #pragma unroll
-            for (int u = 0; u < PT; ++u) { if (key[u] != 0xFFFFFFFFu) atomicAdd(&kcnt[key[u]], 1u); }
+            for (int u = 0; u < PT; ++u) atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
             double xn[PT]; // the next tile is in flight while this one is sorted
-            unsigned kn[PT];
+            {
+                const long long nb = tile0 + TILE;
+                const unsigned nl2 = (nb < n) ? (unsigned)(n - 1 - nb) : 0u;
+                const long long nb2 = (nb < n) ? nb : 0;
 #pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const long long e = tile0 + TILE + (long long)u * NT + tid;
-                kn[u] = (e < n) ? (unsigned)kbuf[e] : (unsigned)CLS_NAN;
-                xn[u] = (e < n) ? vg(e) : 0.0;
+                for (int u = 0; u < PT; ++u) {
+                    unsigned i = (unsigned)(u * NT + tid);
+                    i = i < nl2 ? i : nl2;
+                    kv[u] = (unsigned)(kbuf + nb2)[i];
+                    xn[u] = vg.at(nb2, i);
+                }
             }
-            __syncthreads();
+            wg_barrier_lds();
+#ifdef MDT_PROF_T
+            MDT_PROF_MARK(14);
+#endif
+
             {
                 const unsigned c = (tid < NKEY) ? kcnt[tid] : 0u;
-                unsigned incl = c;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+                const unsigned incl = wave_incl_scan_u32(c);
                 unsigned woff = 0;
                 if (NKEY > 64) {
                     if (lane == 63) wtot[w] = incl;
-                    __syncthreads();
+                    wg_barrier_lds();
+#ifdef MDT_PROF_T
+            MDT_PROF_MARK(15);
+#endif
+
                     for (int q = 0; q < w; ++q) woff += wtot[q];
                 }
                 if (tid < NKEY) {
@@ -1384,20 +1424,33 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                     kcnt[tid] = 0u;
                 }
             }
-            __syncthreads();
+            wg_barrier_lds();
+#ifdef MDT_PROF_T
+            MDT_PROF_MARK(15);
+#endif
+
             unsigned slot[PT];
 #pragma unroll
-            for (int u = 0; u < PT; ++u) { slot[u] = 0u; if (key[u] != 0xFFFFFFFFu) slot[u] = koff[key[u]] + atomicAdd(&kcnt[key[u]], 1u); }
+            for (int u = 0; u < PT; ++u) slot[u] = atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
 #pragma unroll
             for (int u = 0; u < PT; ++u) {
-                if (key[u] != 0xFFFFFFFFu) {
-                    tx[slot[u]] = xv[u];
-                    const unsigned e = (unsigned)(tile0 + (long long)u * NT + tid);
-                    te[slot[u]] = segout ? e - e0tab[kv[u] >> 9 & 63u] : e; // segmented: draw index inside the split chain
-                    tk[slot[u]] = (unsigned short)kv[u];
-                }
+                const unsigned k = key[u] & 0xFFFFu;
+                const unsigned o = keep(koff[k]);
+                slot[u] = (k == (unsigned)KDUMMY) ? (unsigned)TILE : o + slot[u];
             }
-            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const unsigned e = (unsigned)tile0 + (unsigned)(u * NT + tid);
+                const unsigned tag = key[u] >> 16;
+                tx[slot[u]] = xv[u];
+                te[slot[u]] = e - e0tab[tag >> 9 & 63u]; // segmented: draw index inside the split chain (the table is 0 otherwise)
+                tk[slot[u]] = (unsigned short)tag;
+            }
+            wg_barrier_lds();
+#ifdef MDT_PROF_T
+            MDT_PROF_MARK(7);
+#endif
+
             for (int k = w; k < NKEY; k += NWAVE) {
                 const unsigned cnt = kcnt[k], o = koff[k], g = kg[k];
                 if (segout) {
@@ -1416,11 +1469,17 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 }
                 if (lane == 0) kcnt[k] = 0u;
             }
-            __syncthreads();
+            if (tid == 0) kcnt[KDUMMY] = 0u;
+            wg_barrier_lds();
+#ifdef MDT_PROF_T
+            MDT_PROF_MARK(13);
+#endif
+
 #pragma unroll
-            for (int u = 0; u < PT; ++u) { xv[u] = xn[u]; kv[u] = kn[u]; }
+            for (int u = 0; u < PT; ++u) xv[u] = xn[u];
         }
     }
+    __syncthreads(); // the segments are complete in global memory
     MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 13));
     // ---- level 2: rounds
     const int tid_f = tid;
@@ -1488,9 +1547,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 for (int q = 0; q < 4; ++q) wv[q] = lcur[4 * tid + q];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) { c8[q] = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8[q]; }
-                unsigned incl = tot;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) { const unsigned uu = __shfl_up(incl, o); if (lane >= o) incl += uu; }
+                const unsigned incl = wave_incl_scan_u32(tot);
                 if (lane == 63) wtot[w] = incl;
                 __syncthreads();
                 unsigned woff = 0;
