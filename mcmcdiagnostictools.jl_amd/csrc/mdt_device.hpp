@@ -24,22 +24,24 @@
 // reference's tests demand (test/ess_rhat.jl:167-204: results identical wherever a parameter
 // sits in the batch).
 //
-// The file is included TWICE by mdt_hip.hip, into two namespaces, with two workgroup geometries:
-//   MDT_NT 1024, MDT_LDS_LIMIT 160 KiB  one workgroup per CU: long chains, big FFTs, maxlag up to 1000
-//   MDT_NT  512, MDT_LDS_LIMIT  80 KiB  TWO workgroups per CU, so that the memory-bound phases of one
-//                                       parameter overlap the LDS/VALU-bound phases of another
-// Every constant below derives from those two macros; the host picks the geometry per request.
+// The file is included several times by mdt_hip.hip, into one namespace per workgroup geometry:
+//   MDT_NT 1024, MDT_LDS_LIMIT 160 KiB, 4 waves/SIMD  one workgroup per CU: long chains, big FFTs, maxlag <= 1000
+//   MDT_NT  512, MDT_LDS_LIMIT  80 KiB, 4 waves/SIMD  TWO workgroups per CU: the memory-bound phases of one
+//                                                     parameter overlap the LDS/VALU-bound phases of another
+//   MDT_NT 1024, MDT_LDS_LIMIT  80 KiB, 8 waves/SIMD  two workgroups per CU at 64 VGPRs per thread (half the
+//                                                     per-thread arrays): twice the waves to hide latencies with
+// Every constant below derives from those macros; the host picks the geometry per request.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#if !defined(MDT_NS) || !defined(MDT_NT) || !defined(MDT_LDS_LIMIT)
-#error "define MDT_NS, MDT_NT and MDT_LDS_LIMIT before including mdt_device.hpp"
+#if !defined(MDT_NS) || !defined(MDT_NT) || !defined(MDT_LDS_LIMIT) || !defined(MDT_WAVES_PER_EU)
+#error "define MDT_NS, MDT_NT, MDT_LDS_LIMIT and MDT_WAVES_PER_EU before including mdt_device.hpp"
 #endif
 
 namespace MDT_NS {
 
 constexpr int NT = MDT_NT;          // threads per workgroup
-constexpr bool SMALL = (MDT_NT == 512);
+constexpr bool SMALL = (MDT_LDS_LIMIT <= 80 * 1024); // the 80 KiB tables (two workgroups per CU)
 constexpr int NWAVE = NT / 64;      // 16 or 8 wave64
 constexpr int K1 = NT / 4;          // coarse buckets (sample quantiles): every 4th of the NT sorted sample values
 constexpr int FINE = 32;            // bins per coarse bucket: 1 reserved (== splitter) + 31 linear
@@ -49,7 +51,7 @@ constexpr int BIN_TOPEQ = NREG + 1; // equal to the largest sample value (reserv
 constexpr int BIN_OVER = NREG + 2;  // above the largest sample value
 constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless / stable sortperm)
 constexpr int NBIN = NREG + 4;
-constexpr int CH = SMALL ? 6400 : 13760; // elements of bin-ordered data staged in LDS per round
+constexpr int CH = SMALL ? (MDT_NT == 512 ? 6400 : 4096) : 13760; // elements of bin-ordered data staged in LDS per round
 constexpr int GRID = SMALL ? 1024 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
 constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
 constexpr int TL = SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
@@ -503,7 +505,7 @@ __device__ inline void wg_exscan_bins(unsigned* cur, unsigned* wtot, unsigned to
 //        pickup  posbuf[e] streamed; owners of this round fetch chunk[slot] and store it in time
 //                order (coalesced)
 constexpr int DENSE_IT = (CH + NT - 1) / NT; // slot-order iterations per thread per round
-constexpr int UB = 20;                       // independent loads in flight per thread in the streaming passes
+constexpr int UB = (MDT_WAVES_PER_EU >= 8) ? 10 : 20; // independent loads in flight per thread in the streaming passes
 
 template <typename PT, class VG>
 MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, PT* posbuf_,
@@ -1077,8 +1079,10 @@ MDT_PHASE void rank_phase_p(const KP& kp_, VG vg, long long n_, unsigned char* s
 // A coarse class larger than the chunk (constant data, a huge point mass) falls back to rank_phase_p.
 constexpr int NCLS = K1 + 4;              // 0 under, 1..K1 buckets, K1+1 == top sample, K1+2 over, K1+3 NaN
 constexpr int CLS_NAN = K1 + 3;
-constexpr int NBL = NT * 8;               // local fine bins per round (8 per thread in the prefix step)
-constexpr int QCH = SMALL ? 7104 : 15104;  // chunk slots of the two-level variant
+constexpr int NBL = SMALL ? 4096 : 8192;      // local fine bins per round
+constexpr int BPT = NBL / NT;             // bins per thread in the prefix step (packed two per word)
+static_assert(BPT == 8 || BPT == 4, "prefix step: 4 or 8 bins per thread");
+constexpr int QCH = SMALL ? (MDT_NT == 512 ? 7104 : 6720) : 15104; // chunk slots of the two-level variant
 constexpr int DENSE_ITQ = (QCH + NT - 1) / NT;
 constexpr int OFF_QT = OFF_BIG;                               // double t[K1+2]
 constexpr int OFF_QIW = OFF_QT + (K1 + 2) * 8;                // double invw[K1]
@@ -1110,7 +1114,7 @@ __device__ __forceinline__ int class_of(double v, const BinCtx& bc, const double
 // that is counting-sorted by (round [, split chain]) in LDS, so that every run leaves for global memory
 // as a contiguous, fully coalesced stream.  The (split chain x class) counters of the histogram pass
 // live in the same bytes before the first tile arrives.
-constexpr int PT = 8;                                          // elements per thread per tile
+constexpr int PT = (SMALL && MDT_NT == 1024) ? 4 : 8;          // elements per thread per tile
 constexpr int TILE = NT * PT;
 constexpr int SEGKEYS = 128;                                   // (round, split chain) keys of a segmented output
 constexpr int KMAX = 256;                                      // partition keys (>= MAXROUNDS, >= SEGKEYS)
@@ -1127,7 +1131,6 @@ constexpr int OFF_TE = OFF_TX + (TILE + 2) * 8;                // uint32 te[TILE
 constexpr int OFF_TK = OFF_TE + (TILE + 2) * 4;                // uint16 tk[TILE+2]
 constexpr int OFF_CC2 = OFF_TX;                                // uint32 cc2[NJ][NCLS] (histogram pass only)
 static_assert(OFF_TK + (TILE + 2) * 2 <= LDS_BYTES, "partition tile exceeds the LDS carve");
-static_assert(64 * NCLS * 4 <= TILE * 14, "class x chain counters must fit the tile bytes");
 // element tag (kbuf / ksbuf, 16 bits): class (9 bits) | split-chain slot (6 bits) << 9 | first-row flag << 15
 constexpr int TAG_CLS = 511;
 
@@ -1238,7 +1241,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     // split-chain slots per class in the histogram: m real ones + 1 for dropped rows
     const int out_req = uni(out_req_);
     const int NJ = (out_req && kp.m + 1 <= 64) ? kp.m + 1 : 1; // slots the elements are tagged with
-    const int NJc = (out_req == 1) ? NJ : 1;                    // slots the class histogram is kept for (segment sizes)
+    const int NJc = (out_req == 1 && (NJ * NCLS + 1) * 4 <= TILE * 14) ? NJ : 1; // slots the class histogram is kept for (segment sizes)
     const bool momout = out_req == 2 && NJ > 1;
     // moments-only view of the mean_j / var_j bytes while the rounds run (65 slots each)
     long long* mS1 = (long long*)(smem + OFF_MEAN);
@@ -1626,12 +1629,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             MDT_PROF_QMARK(14);
             // exclusive prefix over the packed 16-bit counters; mark bin starts (and reserved bins)
             {
-                unsigned wv[4], c8[8], s8[8];
+                unsigned wv[BPT / 2], c8[BPT], s8[BPT];
                 unsigned tot = 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) wv[q] = lcur[4 * tid + q];
+                for (int q = 0; q < BPT / 2; ++q) wv[q] = lcur[(BPT / 2) * tid + q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { c8[q] = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8[q]; }
+                for (int q = 0; q < BPT; ++q) { c8[q] = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8[q]; }
                 const unsigned incl = wave_incl_scan_u32(tot);
                 if (lane == 63) wtot[w] = incl;
                 __syncthreads();
@@ -1639,13 +1642,13 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 for (int q = 0; q < w; ++q) woff += wtot[q];
                 const unsigned b0 = woff + incl - tot;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) lcur[4 * tid + q] = (b0 + s8[2 * q]) | ((b0 + s8[2 * q + 1]) << 16);
+                for (int q = 0; q < BPT / 2; ++q) lcur[(BPT / 2) * tid + q] = (b0 + s8[2 * q]) | ((b0 + s8[2 * q + 1]) << 16);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
+                for (int q = 0; q < BPT; ++q) {
                     if (c8[q]) {
                         const unsigned st = b0 + s8[q];
                         atomicOr(&bst[st >> 5], 1u << (st & 31));
-                        if (((8 * tid + q) % F2) == 0) atomicOr(&brs[st >> 5], 1u << (st & 31));
+                        if (((BPT * tid + q) % F2) == 0) atomicOr(&brs[st >> 5], 1u << (st & 31));
                     }
                 }
             }
@@ -2114,7 +2117,7 @@ MDT_PHASE SeriesOut series_phase(const KP& kp_, YF Y, bool want_acov_, unsigned 
 //   head_k / tail_k = sums of the first / last k values.  With |mu| << sd this loses nothing
 //   ("one-pass centring"); the reference's two-pass order (src/ess_rhat.jl:529-548) is
 //   kept for raw draws in series_phase, where offsets can be large.
-constexpr int SZ = 6400;                  // doubles per buffer: niter + lag halo must fit
+constexpr int SZ = (SMALL && MDT_NT == 1024) ? 6336 : 6400; // doubles per buffer: niter + lag halo must fit
 constexpr int ZNBUF = SMALL ? 1 : 2;      // LDS buffers: double buffered where the LDS allows (one barrier per chain instead of two)
 constexpr int SZ_EDGE = 256;              // first / last values kept for head_k / tail_k (maxlag <= 255)
 constexpr int LD = (SZ + NT - 1) / NT;    // values per thread
@@ -2830,7 +2833,7 @@ __device__ __forceinline__ void store_out(void* p, long long i, double v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) void mdt_kernel(const KP* __restrict__ kpp) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PER_EU, MDT_WAVES_PER_EU))) void mdt_kernel(const KP* __restrict__ kpp) {
     const KP& kp = *kpp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;

@@ -11,17 +11,24 @@
 #define MDT_NS mdt_big
 #define MDT_NT 1024
 #define MDT_LDS_LIMIT (160 * 1024)
+#define MDT_WAVES_PER_EU 4
 #include "mdt_device.hpp"
 #undef MDT_NS
 #undef MDT_NT
 #undef MDT_LDS_LIMIT
+#undef MDT_WAVES_PER_EU
 #define MDT_NS mdt_small
 #define MDT_NT 512
 #define MDT_LDS_LIMIT (80 * 1024)
+#define MDT_WAVES_PER_EU 4
 #include "mdt_device.hpp"
 #undef MDT_NS
 #undef MDT_NT
 #undef MDT_LDS_LIMIT
+#undef MDT_WAVES_PER_EU
+// (a third geometry -- 1024 threads, 80 KiB, 8 waves/SIMD at 64 VGPRs -- compiles from the same header and
+// passes every test; measured 23.7 ms against 18.3 ms on the headline shape: the barrier-heavy partition and
+// the register-hungry lag products lose more than the count / histogram passes gain.  Not instantiated.)
 #include "mdt_hip.h"
 
 #include <cmath>
@@ -170,7 +177,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
                             D <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
-    const bool small = ctx->force_cfg == 2 ? small_fits : (ctx->force_cfg == 1 ? false : small_fits);
+    const bool small = ctx->force_cfg == 1 ? false : small_fits; // 80 KiB tables, two workgroups per CU
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)a->stream;
