@@ -232,7 +232,8 @@ struct SerZ {          // series = normal scores, already in time order in the p
 };
 #define MDT_PHASE __device__ __attribute__((noinline))
 // Keeps a loaded value "used" so that the compiler cannot sink the load under the condition of a later
-// select (it then branches around every single LDS read and waits for each one separately).
+// select (it then branches around every single LDS read and waits for each one separately).  Call it in a
+// SECOND loop, after all the loads of a batch were issued: the value must be in its register at the asm.
 __device__ __forceinline__ unsigned keep(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ double keep(double v) { asm volatile("" : "+v"(v)); return v; }
 
@@ -506,6 +507,7 @@ __device__ inline void wg_exscan_bins(unsigned* cur, unsigned* wtot, unsigned to
 //                order (coalesced)
 constexpr int DENSE_IT = (CH + NT - 1) / NT; // slot-order iterations per thread per round
 constexpr int UB = (MDT_WAVES_PER_EU >= 8) ? 10 : 20; // independent loads in flight per thread in the streaming passes
+constexpr int UBH = 10;                      // ... in the histogram pass (value, bracket and probe of every element are live together)
 
 template <typename PT, class VG>
 MDT_PHASE void rank_phase_b(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, PT* posbuf_,
@@ -1301,39 +1303,46 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     MDT_PROF_MARK(PH_R_SAMPLE);
 
     // ---- level 1: coarse histogram per (split-chain slot, class): the HBM read of x
-    // Straight-line per batch: every value takes the same `nsteps` search steps, so the LDS reads of the UB
+    // Straight-line per batch: every value takes the same `nsteps` search steps, so the LDS reads of the UBH
     // values of a thread overlap; slots past the end of the slice count into a dummy counter.
     {
         SplitIter sp;
         sp.D = uD; sp.niter = uniter; sp.rem = urem; sp.s = us; sp.m = um;
-        for (long long b0 = 0; b0 < n; b0 += step) {
-            const unsigned left = (unsigned)((n - b0 < step) ? n - b0 : step);
-            double xb[UB];
+        for (long long b0 = 0; b0 < n; b0 += (long long)NT * UBH) {
+            const unsigned left = (unsigned)((n - b0 < (long long)NT * UBH) ? n - b0 : (long long)NT * UBH);
+            double xb[UBH];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) {
                 const unsigned i = (unsigned)(u * NT + tid);
                 xb[u] = vg.at(b0, i < left ? i : left - 1u);
             }
-            unsigned lh[UB];
+            unsigned lh[UBH];
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) {
                 double vc = (xb[u] >= bc.t0) ? xb[u] : bc.t0; // (NaN -> t0)
                 vc = vc < bc.top ? vc : bc.top;
-                lh[u] = keep(lut[cell_of(vc, bc.t0, bc.ginv)]);
+                lh[u] = lut[cell_of(vc, bc.t0, bc.ginv)];
             }
-            for (int st = 0; st < nsteps; ++st) {
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) lh[u] = keep(lh[u]);
+            for (int st = 0; st < nsteps; ++st) {
+                double tm[UBH];
+#pragma unroll
+                for (int u = 0; u < UBH; ++u) tm[u] = qt[((lh[u] & 0xFFFFu) + (lh[u] >> 16) + 1u) >> 1];
+#pragma unroll
+                for (int u = 0; u < UBH; ++u) tm[u] = keep(tm[u]);
+#pragma unroll
+                for (int u = 0; u < UBH; ++u) {
                     const unsigned lo = lh[u] & 0xFFFFu, hi = lh[u] >> 16;
                     const unsigned mid = (lo + hi + 1u) >> 1;
-                    const bool up = keep(qt[mid]) <= xb[u];
+                    const bool up = tm[u] <= xb[u];
                     lh[u] = up ? (mid | (hi << 16)) : (lo | ((lo < hi ? mid - 1u : hi) << 16));
                 }
             }
-            unsigned kq[UB];
+            unsigned kq[UBH];
             if (NJ > 1) sp.init((unsigned)b0 + (unsigned)tid);
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) {
                 const double v = xb[u];
                 unsigned cls = 1u + (lh[u] & 0xFFFFu);
                 cls = (v < bc.t0) ? 0u : cls;
@@ -1343,12 +1352,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 if (NJ > 1) { kq[u] |= sp.tag(); sp.advance((unsigned)NT); }
             }
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) {
                 const bool ok = (unsigned)(u * NT + tid) < left;
                 atomicAdd(&cc2[ok ? (NJc > 1 ? (kq[u] >> 9 & 63u) * NCLS : 0u) + (kq[u] & TAG_CLS) : (unsigned)(NJc * NCLS)], 1u);
             }
 #pragma unroll
-            for (int u = 0; u < UB; ++u) {
+            for (int u = 0; u < UBH; ++u) {
                 const unsigned i = (unsigned)(u * NT + tid);
                 if (i < left) (kbuf + b0)[i] = (unsigned short)kq[u];
             }
@@ -1461,9 +1470,15 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
 #pragma unroll
             for (int u = 0; u < PT; ++u) {
                 const unsigned cls = kv[u] & TAG_CLS;
+                key[u] = (unsigned)rof[cls < (unsigned)CLS_NAN ? cls : 0u];
+            }
+#pragma unroll
+            for (int u = 0; u < PT; ++u) key[u] = keep(key[u]);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) {
+                const unsigned cls = kv[u] & TAG_CLS;
                 const bool ok = (unsigned)(u * NT + tid) < left && cls < (unsigned)CLS_NAN;
-                const unsigned r = keep((unsigned)rof[ok ? cls : 0u]);
-                key[u] = (ok ? r * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : (unsigned)KDUMMY) | (kv[u] << 16);
+                key[u] = (ok ? key[u] * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : (unsigned)KDUMMY) | (kv[u] << 16);
             }
 #pragma unroll
             for (int u = 0; u < PT; ++u) atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
@@ -1516,11 +1531,11 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
 #pragma unroll
             for (int u = 0; u < PT; ++u) slot[u] = atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
 #pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const unsigned k = key[u] & 0xFFFFu;
-                const unsigned o = keep(koff[k]);
-                slot[u] = (k == (unsigned)KDUMMY) ? (unsigned)TILE : o + slot[u];
-            }
+            for (int u = 0; u < PT; ++u) slot[u] += koff[key[u] & 0xFFFFu];
+#pragma unroll
+            for (int u = 0; u < PT; ++u) slot[u] = keep(slot[u]);
+#pragma unroll
+            for (int u = 0; u < PT; ++u) slot[u] = ((key[u] & 0xFFFFu) == (unsigned)KDUMMY) ? (unsigned)TILE : slot[u];
 #pragma unroll
             for (int u = 0; u < PT; ++u) {
                 const unsigned e = (unsigned)tile0 + (unsigned)(u * NT + tid);
