@@ -2679,7 +2679,7 @@ constexpr int IND_MAXW = SMALL ? 1024 : 1536; // words of the pooled stream per 
 constexpr int IND_CB = SMALL ? 8 : 16; // split chains per batch (2 indicators x 16 chains = 32 units)
 constexpr int OFF_PBITS = OFF_BIG;                           // uint64 pbits[2][IND_MAXW]
 constexpr int OFF_SB2 = OFF_PBITS + 2 * IND_MAXW * 8;        // uint64 sb2[SB2_WORDS]: units packed with stride nwS
-constexpr int SB2_WORDS = SMALL ? 2048 : 4096;
+constexpr int SB2_WORDS = SMALL ? 2048 : 4096;           // (>= 2 units of up to IND_MAXW + maxlag/64 + 2 words: checked by the host limits)
 constexpr int OFF_ITAB = OFF_SB2 + SB2_WORDS * 8;            // double itab[2][2*IND_CB][64] (cov, dif)
 constexpr int OFF_ICNT2 = OFF_ITAB + 2 * 2 * IND_CB * 64 * 8; // double icov[2][NLAGTAB], idif[2][NLAGTAB], imean[2][MAXM]
 constexpr int LDS_IND2_END = OFF_ICNT2 + (4 * NLAGTAB + 2 * MAXM) * 8;
@@ -2727,38 +2727,61 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
     while (true) {
         long long kend = k0 + 64;
         if (kend > maxlag + 1) kend = maxlag + 1;
-        int cb = SB2_WORDS / (2 * nwS);
+        // units (chain, indicator) are stored with a stride of nwU words: nwS words of bits (tail masked) and
+        // zero words behind them, so that a shifted read never needs a bounds check
+        const int nwU = nwS + (int)(maxlag >> 6) + 2;
+        int cb = SB2_WORDS / (2 * nwU);
         cb = cb < 1 ? 1 : (cb > IND_CB ? IND_CB : cb);
         for (int jb = 0; jb < m; jb += cb) {
             const int nb = (m - jb < cb) ? m - jb : cb;
             // split-aligned words of nb chains x 2 indicators
-            for (int i = tid; i < 2 * nb * nwS; i += NT) {
-                const int u = i / nwS, wi = i - u * nwS;      // u = 2*jl + ind
+            for (int i = tid; i < 2 * nb * nwU; i += NT) {
+                const int u = i / nwU, wi = i - u * nwU;      // u = 2*jl + ind
                 const int jl = u >> 1, ind = u & 1;
                 const int j2 = jb + jl, c = j2 / s, kk = j2 - c * s;
                 const long long pos = (long long)c * D + split_row0(kk, niter, kp.rem) + ((long long)wi << 6);
-                unsigned long long v = bits_at(pbits + ind * IND_MAXW, pos, nwP);
+                unsigned long long v = (wi < nwS) ? bits_at(pbits + ind * IND_MAXW, pos, nwP) : 0ull;
                 const long long left = niter - ((long long)wi << 6);
                 if (left < 64) v &= (left <= 0) ? 0ull : ((1ull << left) - 1ull);
-                sb2[u * nwS + wi] = v;
+                sb2[u * nwU + wi] = v;
             }
             __syncthreads();
             for (int u = w; u < 2 * nb; u += NWAVE) {
-                const unsigned long long* sb = sb2 + u * nwS;
+                const unsigned long long* sb = sb2 + u * nwU;
                 const long long k = k0 + lane;
                 long long Sx = 0, Ak = 0, Hk = 0, Tk = 0;
                 double ck = 0.0, dk = 0.0;
                 if (k < kend) {
+                    // A_k = sum_t I_t I_{t+k}: the only sum that needs the whole chain per lag.  S is the same
+                    // for every lag; T_k = ones in [k, n) = S - ones in [0, k); H_k = ones in [0, n-k) =
+                    // S - ones in [n-k, n): a few words each.
+                    const int q = (int)(k >> 6), r = (int)(k & 63);
+                    unsigned long long lo = sb[q];
                     for (int i = 0; i < nwS; ++i) {
                         const unsigned long long v = sb[i];
-                        const unsigned long long vs = bits_at(sb, ((long long)i << 6) + k, nwS);
-                        const long long cnt = niter - (((long long)i << 6) + k);
-                        const unsigned long long ms = cnt >= 64 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));
+                        const unsigned long long hi = sb[i + q + 1];
+                        const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
                         Sx += __popcll(v);
                         Ak += __popcll(v & vs);
-                        Tk += __popcll(vs);
-                        Hk += __popcll(v & ms);
+                        lo = hi;
                     }
+                    long long head = 0, tail = 0; // ones among the first k / the last k positions
+                    for (int i = 0; i <= q; ++i) {
+                        const long long nb2 = k - ((long long)i << 6); // bits of word i that belong to [0, k)
+                        const unsigned long long mk = nb2 >= 64 ? ~0ull : (nb2 <= 0 ? 0ull : ((1ull << nb2) - 1ull));
+                        head += __popcll(sb[i] & mk);
+                    }
+                    {
+                        const long long p0 = niter - k; // first position of the tail
+                        for (int i = (int)((p0 > 0 ? p0 : 0) >> 6); i < nwS; ++i) {
+                            const long long b0 = (long long)i << 6; // positions b0 .. b0+63
+                            const long long sk = p0 - b0;           // bits below sk are not in the tail
+                            const unsigned long long mk = sk <= 0 ? ~0ull : (sk >= 64 ? 0ull : ~((1ull << sk) - 1ull));
+                            tail += __popcll(sb[i] & mk);
+                        }
+                    }
+                    Tk = Sx - head;
+                    Hk = Sx - tail;
                     const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
                     ck = (double)N / (dn * dn);
                     // FFTAutocovMethod normalises by the lag-0 value of the same chain: 0/0 -> NaN for a
@@ -3089,7 +3112,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         if (kp.need_et && kp.ess_ok) {
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
-            else if (n <= (long long)IND_MAXW * 64) et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem);
+            else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
+                et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem);
             else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem);
             MDT_PROF_MARK(PH_IND);
         }
