@@ -1112,27 +1112,19 @@ __device__ __forceinline__ int class_of(double v, const BinCtx& bc, const double
     return 1 + lo;
 }
 
-// Partition-time view of the region above the class tables: one tile of (value, index, class) records
-// that is counting-sorted by (round [, split chain]) in LDS, so that every run leaves for global memory
-// as a contiguous, fully coalesced stream.  The (split chain x class) counters of the histogram pass
-// live in the same bytes before the first tile arrives.
-constexpr int PT = (SMALL && MDT_NT == 1024) ? 4 : 8;          // elements per thread per tile
-constexpr int TILE = NT * PT;
+// Partition-time view of the region above the class tables: the cursors of the (round [, split chain])
+// segments; the (split chain x class) counters of the histogram pass and the sample buffer live above them.
 constexpr int SEGKEYS = 128;                                   // (round, split chain) keys of a segmented output
 constexpr int KMAX = 256;                                      // partition keys (>= MAXROUNDS, >= SEGKEYS)
 static_assert(KMAX >= MAXROUNDS && KMAX >= SEGKEYS && KMAX <= NT, "partition key tables");
-constexpr int OFF_TSEG = OFF_QCUR;                             // uint32 segcur[KMAX]: global cursor of every key (round-major)
-constexpr int KDUMMY = KMAX;                                   // key of a slot past the end of the slice (never read back)
-constexpr int OFF_TSEG2 = OFF_TSEG + KMAX * 4;                 // uint32 segcur2[KMAX]: the same in chain-major order
-constexpr int OFF_TCNT = OFF_TSEG2 + KMAX * 4;                 // uint32 kcnt[KMAX+4]: count / placement cursor of the tile
-constexpr int OFF_TOFF = OFF_TCNT + (KMAX + 4) * 4;            // uint32 koff[KMAX+4]: start of the key's run inside the tile
-constexpr int OFF_TGB = OFF_TOFF + (KMAX + 4) * 4;             // uint32 kg[KMAX]: global destination of the key's run
-constexpr int OFF_TGB2 = OFF_TGB + KMAX * 4;                   // uint32 kg2[KMAX]: chain-major destination of the key's run
-constexpr int OFF_TX = ((OFF_TGB2 + KMAX * 4 + 15) / 16) * 16; // double tx[TILE+2]  (+ a dump record for dummy keys)
-constexpr int OFF_TE = OFF_TX + (TILE + 2) * 8;                // uint32 te[TILE+2]
-constexpr int OFF_TK = OFF_TE + (TILE + 2) * 4;                // uint16 tk[TILE+2]
-constexpr int OFF_CC2 = OFF_TX;                                // uint32 cc2[NJ][NCLS] (histogram pass only)
-static_assert(OFF_TK + (TILE + 2) * 2 <= LDS_BYTES, "partition tile exceeds the LDS carve");
+constexpr int KDUMMY = KMAX;                                   // key of a slot past the end of the slice / of a NaN
+constexpr int OFF_TSEG = OFF_QCUR;                             // uint32 segcur[KMAX]: cursor of every segment (round-major order)
+constexpr int OFF_TSEG2 = OFF_TSEG + KMAX * 4;                 // uint32 segcur2[KMAX]: start of every segment in chain-major order
+constexpr int OFF_TGB2 = OFF_TSEG2 + KMAX * 4;                 // uint32 kg2[KMAX]: chain-major place = round-major place + kg2[key]
+constexpr int OFF_TX = ((OFF_TGB2 + KMAX * 4 + 15) / 16) * 16; // double tx[NT]: sample buffer; then
+constexpr int OFF_CC2 = OFF_TX;                                // uint32 cc2[NJ][NCLS] + 1 (histogram pass only)
+constexpr int CC2_BYTES = LDS_BYTES - OFF_CC2;
+static_assert(NT * 8 <= CC2_BYTES, "sample buffer exceeds the LDS carve");
 // element tag (kbuf / ksbuf, 16 bits): class (9 bits) | split-chain slot (6 bits) << 9 | first-row flag << 15
 constexpr int TAG_CLS = 511;
 
@@ -1230,20 +1222,15 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     double* chunk = (double*)(smem + OFF_QCHUNK);
     unsigned* cc2 = (unsigned*)(smem + OFF_CC2);
     unsigned* segcur = (unsigned*)(smem + OFF_TSEG);
-    unsigned* kcnt = (unsigned*)(smem + OFF_TCNT);
-    unsigned* koff = (unsigned*)(smem + OFF_TOFF);
-    unsigned* kg = (unsigned*)(smem + OFF_TGB);
     unsigned* segcur2 = (unsigned*)(smem + OFF_TSEG2);
     unsigned* kg2 = (unsigned*)(smem + OFF_TGB2);
     MDT_GA unsigned short* locbuf = (MDT_GA unsigned short*)esbuf; // segmented output: draw index of every member, chain-major
     double* tx = (double*)(smem + OFF_TX);
-    unsigned* te = (unsigned*)(smem + OFF_TE);
-    unsigned short* tk = (unsigned short*)(smem + OFF_TK);
     const unsigned uD = (unsigned)kp.D, uniter = (unsigned)kp.niter, urem = (unsigned)kp.rem, us = (unsigned)kp.s, um = (unsigned)kp.m;
     // split-chain slots per class in the histogram: m real ones + 1 for dropped rows
     const int out_req = uni(out_req_);
     const int NJ = (out_req && kp.m + 1 <= 64) ? kp.m + 1 : 1; // slots the elements are tagged with
-    const int NJc = (out_req == 1 && (NJ * NCLS + 1) * 4 <= TILE * 14) ? NJ : 1; // slots the class histogram is kept for (segment sizes)
+    const int NJc = (out_req == 1 && (NJ * NCLS + 1) * 4 <= CC2_BYTES) ? NJ : 1; // slots the class histogram is kept for (segment sizes)
     const bool momout = out_req == 2 && NJ > 1;
     // moments-only view of the mean_j / var_j bytes while the rounds run (65 slots each)
     long long* mS1 = (long long*)(smem + OFF_MEAN);
@@ -1432,7 +1419,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         unsigned woff = 0;
         for (int q = 0; q < w; ++q) woff += wtot[q];
         const unsigned start = woff + incl - cnt;
-        if (tid < KMAX) { segcur[tid] = start; kcnt[tid] = 0u; }
+        if (tid < KMAX) segcur[tid] = start;
         if (segout && tid <= NKEY) segsave[tid] = (tid < NKEY) ? start : (unsigned)n;
         if (tid < 68) {
             const unsigned c = (unsigned)tid / us, kk = (unsigned)tid - c * us;
@@ -1448,133 +1435,50 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         segcur2[tid] = (unsigned)j * uniter + cum;
     }
     __syncthreads();
-    // ---- partition, tile by tile: count keys, prefix, place in LDS, stream every run out.
-    // Straight-line code: slots past the end of the slice (last tile) and NaNs carry the dummy key, their
-    // record lands in a dump slot; every LDS access of the 8 elements of a thread is issued back to back.
+    // ---- partition: every element draws its place in its key's segment with one returning LDS atomic on the
+    // segment cursor and is stored there; lanes of a wave that share a key draw neighbouring places, so the
+    // stores still fill whole cache lines.  (Counting-sorting tiles of 8*NT records in LDS first, so that every
+    // key's run leaves as one contiguous stream, was measured too: 17.0 ms against 16.8 ms -- the extra LDS
+    // traffic and four barriers per tile cost more than the better-formed stores save.)
     {
-        if (tid == 0) { kcnt[KDUMMY] = 0u; koff[KDUMMY] = (unsigned)TILE; }
-        double xv[PT];
-        unsigned kv[PT];
-        const unsigned nlast = (unsigned)(n - 1);
+        if (segout && tid < NKEY) kg2[tid] = segcur2[tid] - segcur[tid]; // chain-major place = place + kg2[key]
+        __syncthreads();
+        constexpr int UP = 10;
+        for (long long b0 = 0; b0 < n; b0 += (long long)NT * UP) {
+            const unsigned left = (unsigned)((n - b0 < (long long)NT * UP) ? n - b0 : (long long)NT * UP);
+            double xv[UP];
+            unsigned kv[UP], key[UP], off[UP];
 #pragma unroll
-        for (int u = 0; u < PT; ++u) {
-            unsigned i = (unsigned)(u * NT + tid);
-            i = i < nlast ? i : nlast;
-            kv[u] = (unsigned)kbuf[i];
-            xv[u] = vg.at(0, i);
-        }
-        wg_barrier_lds();
-        for (long long tile0 = 0; tile0 < n; tile0 += TILE) {
-            const unsigned left = (unsigned)((n - tile0 < TILE) ? n - tile0 : TILE); // valid slots of this tile
-            unsigned key[PT]; // key | class tag << 16
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const unsigned cls = kv[u] & TAG_CLS;
-                key[u] = (unsigned)rof[cls < (unsigned)CLS_NAN ? cls : 0u];
+            for (int u = 0; u < UP; ++u) {
+                unsigned i = (unsigned)(u * NT + tid);
+                i = i < left ? i : left - 1u;
+                kv[u] = (unsigned)(kbuf + b0)[i];
+                xv[u] = vg.at(b0, i);
             }
 #pragma unroll
-            for (int u = 0; u < PT; ++u) key[u] = keep(key[u]);
+            for (int u = 0; u < UP; ++u) { const unsigned cls = kv[u] & TAG_CLS; key[u] = (unsigned)rof[cls < (unsigned)CLS_NAN ? cls : 0u]; }
 #pragma unroll
-            for (int u = 0; u < PT; ++u) {
+            for (int u = 0; u < UP; ++u) key[u] = keep(key[u]);
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
                 const unsigned cls = kv[u] & TAG_CLS;
                 const bool ok = (unsigned)(u * NT + tid) < left && cls < (unsigned)CLS_NAN;
-                key[u] = (ok ? key[u] * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : (unsigned)KDUMMY) | (kv[u] << 16);
+                key[u] = ok ? key[u] * (unsigned)NJe + (segout ? (kv[u] >> 9 & 63u) : 0u) : (unsigned)KDUMMY;
             }
 #pragma unroll
-            for (int u = 0; u < PT; ++u) atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
-            double xn[PT]; // the next tile is in flight while this one is sorted
-            {
-                const long long nb = tile0 + TILE;
-                const unsigned nl2 = (nb < n) ? (unsigned)(n - 1 - nb) : 0u;
-                const long long nb2 = (nb < n) ? nb : 0;
+            for (int u = 0; u < UP; ++u) off[u] = atomicAdd(&segcur[key[u] < (unsigned)KDUMMY ? key[u] : (unsigned)(KMAX - 1)], key[u] < (unsigned)KDUMMY ? 1u : 0u);
 #pragma unroll
-                for (int u = 0; u < PT; ++u) {
-                    unsigned i = (unsigned)(u * NT + tid);
-                    i = i < nl2 ? i : nl2;
-                    kv[u] = (unsigned)(kbuf + nb2)[i];
-                    xn[u] = vg.at(nb2, i);
+            for (int u = 0; u < UP; ++u) off[u] = keep(off[u]);
+#pragma unroll
+            for (int u = 0; u < UP; ++u) {
+                if (key[u] < (unsigned)KDUMMY) {
+                    const unsigned e = (unsigned)b0 + (unsigned)(u * NT + tid);
+                    xsbuf[off[u]] = xv[u];
+                    ksbuf[off[u]] = (unsigned short)kv[u];
+                    if (segout) locbuf[off[u] + kg2[key[u]]] = (unsigned short)(e - e0tab[kv[u] >> 9 & 63u]);
+                    else esbuf[off[u]] = e;
                 }
             }
-            wg_barrier_lds();
-#ifdef MDT_PROF_T
-            MDT_PROF_MARK(14);
-#endif
-
-            {
-                const unsigned c = (tid < NKEY) ? kcnt[tid] : 0u;
-                const unsigned incl = wave_incl_scan_u32(c);
-                unsigned woff = 0;
-                if (NKEY > 64) {
-                    if (lane == 63) wtot[w] = incl;
-                    wg_barrier_lds();
-#ifdef MDT_PROF_T
-            MDT_PROF_MARK(15);
-#endif
-
-                    for (int q = 0; q < w; ++q) woff += wtot[q];
-                }
-                if (tid < NKEY) {
-                    koff[tid] = woff + incl - c;
-                    const unsigned g = segcur[tid];
-                    kg[tid] = g;
-                    segcur[tid] = g + c;
-                    if (segout) { const unsigned g2 = segcur2[tid]; kg2[tid] = g2; segcur2[tid] = g2 + c; }
-                    kcnt[tid] = 0u;
-                }
-            }
-            wg_barrier_lds();
-#ifdef MDT_PROF_T
-            MDT_PROF_MARK(15);
-#endif
-
-            unsigned slot[PT];
-#pragma unroll
-            for (int u = 0; u < PT; ++u) slot[u] = atomicAdd(&kcnt[key[u] & 0xFFFFu], 1u);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) slot[u] += koff[key[u] & 0xFFFFu];
-#pragma unroll
-            for (int u = 0; u < PT; ++u) slot[u] = keep(slot[u]);
-#pragma unroll
-            for (int u = 0; u < PT; ++u) slot[u] = ((key[u] & 0xFFFFu) == (unsigned)KDUMMY) ? (unsigned)TILE : slot[u];
-#pragma unroll
-            for (int u = 0; u < PT; ++u) {
-                const unsigned e = (unsigned)tile0 + (unsigned)(u * NT + tid);
-                const unsigned tag = key[u] >> 16;
-                tx[slot[u]] = xv[u];
-                te[slot[u]] = e - e0tab[tag >> 9 & 63u]; // segmented: draw index inside the split chain (the table is 0 otherwise)
-                tk[slot[u]] = (unsigned short)tag;
-            }
-            wg_barrier_lds();
-#ifdef MDT_PROF_T
-            MDT_PROF_MARK(7);
-#endif
-
-            for (int k = w; k < NKEY; k += NWAVE) {
-                const unsigned cnt = kcnt[k], o = koff[k], g = kg[k];
-                if (segout) {
-                    const unsigned g2 = kg2[k];
-                    for (unsigned i = lane; i < cnt; i += 64u) {
-                        xsbuf[g + i] = tx[o + i];
-                        locbuf[g2 + i] = (unsigned short)te[o + i];
-                        ksbuf[g + i] = tk[o + i];
-                    }
-                } else {
-                    for (unsigned i = lane; i < cnt; i += 64u) {
-                        xsbuf[g + i] = tx[o + i];
-                        esbuf[g + i] = te[o + i];
-                        ksbuf[g + i] = tk[o + i];
-                    }
-                }
-                if (lane == 0) kcnt[k] = 0u;
-            }
-            if (tid == 0) kcnt[KDUMMY] = 0u;
-            wg_barrier_lds();
-#ifdef MDT_PROF_T
-            MDT_PROF_MARK(13);
-#endif
-
-#pragma unroll
-            for (int u = 0; u < PT; ++u) xv[u] = xn[u];
         }
     }
     __syncthreads(); // the segments are complete in global memory
