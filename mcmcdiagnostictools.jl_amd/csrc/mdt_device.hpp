@@ -1517,30 +1517,50 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         {
             double xv[DENSE_ITQ];
             int lb[DENSE_ITQ];
+            {
+                const MDT_GA double* xr = xsbuf + base; // (uniform base + 32-bit lane offsets, clamped: no branches)
+                const MDT_GA unsigned short* kr = ksbuf + base;
 #pragma unroll
-            for (int k = 0; k < DENSE_ITQ; ++k) {
-                const unsigned i = (unsigned)(k * NT + tid);
-                xv[k] = (i < cnt) ? xsbuf[base + i] : 0.0;
-                lb[k] = (i < cnt) ? (int)ksbuf[base + i] : clo;
+                for (int k = 0; k < DENSE_ITQ; ++k) {
+                    unsigned i = (unsigned)(k * NT + tid);
+                    i = i < cnt ? i : cnt - 1u;
+                    xv[k] = xr[i];
+                    lb[k] = (int)kr[i];
+                }
             }
-            // local fine bin: (class - clo) * F2 + sub; sub 0 = equal to the bucket's splitter (reserved)
+            // local fine bin: (class - clo) * F2 + sub; sub 0 = equal to the bucket's splitter (reserved).
+            // Two half-batches: the splitter and scale of every member are read before any is used.
+            constexpr int HB = (DENSE_ITQ + 1) / 2;
 #pragma unroll
-            for (int k = 0; k < DENSE_ITQ; ++k) {
-                fmask |= ((unsigned)lb[k] >> 15 & 1u) << k;
-                jpk[k >> 2] |= ((unsigned)lb[k] >> 9 & 63u) << ((k & 3) << 3);
-                const int cls = lb[k] & TAG_CLS;
-                int sub = 1;
-                if (cls >= 1 && cls <= K1) {
-                    const double tk2 = qt[cls - 1];
-                    const double v = xv[k];
-                    if (v == tk2) sub = 0;
-                    else {
-                        double f = (v - tk2) * qiw[cls - 1] * f2m1;
-                        f = f < (double)(F2 - 2) ? f : (double)(F2 - 2);
-                        sub = 1 + (int)f;
+            for (int h = 0; h < 2; ++h) {
+                double tk2[HB], iw2[HB];
+#pragma unroll
+                for (int kk = 0; kk < HB; ++kk) {
+                    const int k = h * HB + kk;
+                    if (k < DENSE_ITQ) {
+                        const int cls = lb[k] & TAG_CLS;
+                        const int kc = cls < 1 ? 0 : (cls > K1 ? K1 - 1 : cls - 1);
+                        tk2[kk] = qt[kc];
+                        iw2[kk] = qiw[kc];
                     }
-                } else if (cls == K1 + 1) sub = 0;
-                lb[k] = (cls - clo) * F2 + sub;
+                }
+#pragma unroll
+                for (int kk = 0; kk < HB; ++kk) { if (h * HB + kk < DENSE_ITQ) { tk2[kk] = keep(tk2[kk]); iw2[kk] = keep(iw2[kk]); } }
+#pragma unroll
+                for (int kk = 0; kk < HB; ++kk) {
+                    const int k = h * HB + kk;
+                    if (k < DENSE_ITQ) {
+                        fmask |= ((unsigned)lb[k] >> 15 & 1u) << k;
+                        jpk[k >> 2] |= ((unsigned)lb[k] >> 9 & 63u) << ((k & 3) << 3);
+                        const int cls = lb[k] & TAG_CLS;
+                        const double v = xv[k];
+                        double f = (v - tk2[kk]) * iw2[kk] * f2m1;
+                        f = f < (double)(F2 - 2) ? f : (double)(F2 - 2);
+                        const int subr = (v == tk2[kk]) ? 0 : 1 + (int)f;        // inside a regular bucket
+                        const int sub = (cls >= 1 && cls <= K1) ? subr : ((cls == K1 + 1) ? 0 : 1);
+                        lb[k] = (cls - clo) * F2 + sub;
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) atomicAdd(&lcur[lb[k] >> 1], 1u << ((lb[k] & 1) << 4)); }
