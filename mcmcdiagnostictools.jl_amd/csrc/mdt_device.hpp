@@ -1709,12 +1709,22 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             } else if (segout) {
                 // chain-major segment order: every (round, chain) segment is one coalesced stream; the first
                 // draw of every split chain leaves its score in mean_j[] (the shift K_j of series_z_phase)
+                int dst[DENSE_ITQ];
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) dst[k] = adj2[jpk[k >> 2] >> ((k & 3) << 3) & 63u];
+#pragma unroll
+                for (int k = 0; k < DENSE_ITQ; ++k) dst[k] = (int)keep((unsigned)dst[k]);
 #pragma unroll
                 for (int k = 0; k < DENSE_ITQ; ++k) {
                     const unsigned i = (unsigned)(k * NT + tid);
-                    const unsigned j = jpk[k >> 2] >> ((k & 3) << 3) & 63u;
-                    if (i < cnt) zout[(int)i + adj2[j]] = zz[k];
-                    if ((fmask >> k & 1u) && j < um) mean_j[j] = zz[k];
+                    if (i < cnt) zout[(int)i + dst[k]] = zz[k];
+                }
+                if (fmask) {
+#pragma unroll
+                    for (int k = 0; k < DENSE_ITQ; ++k) {
+                        const unsigned j = jpk[k >> 2] >> ((k & 3) << 3) & 63u;
+                        if ((fmask >> k & 1u) && j < um) mean_j[j] = zz[k];
+                    }
                 }
             } else {
                 unsigned ev[DENSE_ITQ];
