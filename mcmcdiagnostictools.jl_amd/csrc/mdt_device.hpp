@@ -1805,7 +1805,7 @@ struct Geyer {
 // lag block, then Geyer's initial monotone sequence (:555-594) over the lags available so far.
 // State between blocks lives in scal[4..6], ints[1] (started), ints[2] (done).
 template <class KPT>
-__device__ inline void series_combine(const KPT& kp, unsigned char* smem, int block, long long kend, bool want_acov) {
+__device__ inline void series_combine(const KPT& kp, unsigned char* smem, int block, long long kend, bool want_acov, bool fft_sums = false) {
     double* scal = (double*)(smem + OFF_SCAL);
     int* ints = (int*)(smem + OFF_INTS);
     double* mean_j = (double*)(smem + OFF_MEAN);
@@ -1836,7 +1836,7 @@ __device__ inline void series_combine(const KPT& kp, unsigned char* smem, int bl
             const double n2 = (double)(niter - k);
             const double sdiff = (2.0 * A[0] - aux[k] - aux[NLAGTAB + k] - 2.0 * A[k]) / dm;
             ma = W - sdiff / (2.0 * n2);
-        } else if (method == 1) {
+        } else if (method == 1 && fft_sums) { // A[k] = sum_j ac_k/ac_0 * var_j from the transform; otherwise plain lag sums
             ma = A[k] / dm * kp.cf; // mean_i(ac_k/ac_0 * var_i) * (niter-1)//niter, src/ess_rhat.jl:191-194
         } else {
             ma = A[k] / dm / dn;
@@ -2444,7 +2444,7 @@ MDT_PHASE SeriesOut series_fft_phase(const KP& kp_, YF Y, unsigned char* smem) {
         if (tid <= maxlag) A[tid] += fb[tid].x / fb[0].x * var_j[j]; // :192, summed over chains in order
         __syncthreads();
     }
-    if (tid == 0) series_combine(kp, smem, 1 /* moments already combined */, maxlag + 1, true);
+    if (tid == 0) series_combine(kp, smem, 1 /* moments already combined */, maxlag + 1, true, true);
     __syncthreads();
     out.rhat = scal[2];
     out.ess = scal[3];
@@ -2889,14 +2889,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             continue;
         }
 
+        // FFTAutocovMethod: the in-LDS transform when the padded chain fits; longer chains get the same linear
+        // autocorrelation from lagged products (zero padding makes the transform's result exactly those sums:
+        // ac_k / ac_0 * var_j * (niter-1)/niter == sum_t c_t c_{t+k} / niter), plus the one place where the
+        // formulas differ: a constant split chain is 0/0 = NaN in the reference (src/ess_rhat.jl:192).
+        const bool fft_lds = kp.method == 1 && kp.niter + kp.maxlag + 1 <= FFT_MAXN;
+        auto fft_const_chain_nan = [&](double ess) -> double {
+            if (kp.method != 1 || fft_lds) return ess;
+            if (tid == 0) {
+                int c0 = 0;
+                for (int j = 0; j < kp.m; ++j) c0 |= (var_j[j] == 0.0) ? 1 : 0;
+                ((int*)(smem + OFF_INTS))[16] = c0;
+            }
+            __syncthreads();
+            const bool anyc = ((int*)(smem + OFF_INTS))[16] != 0;
+            __syncthreads();
+            return anyc ? nan : ess;
+        };
+
         if (kp.basic && kp.mode != 3) {
             const bool acov = kp.need_eb && kp.ess_ok;
             SeriesOut so;
-            if (acov && kp.method == 1) {
+            if (acov && fft_lds) {
                 (void)series_phase(kp, YX, false, smem); // moments -> mean_j / var_j / R-hat
                 so = series_fft_phase(kp, YX, smem);
             } else {
                 so = series_phase(kp, YX, acov, smem);
+                if (acov) so.ess = fft_const_chain_nan(so.ess);
             }
             double ess = acov ? so.ess : nan;
             if (kp.mode == 1) {
@@ -2939,7 +2958,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
         // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
-        const bool seg_req = zfast && kp.method != 1 && kp.mode != 3;
+        const bool seg_req = zfast && !(kp.method == 1 && kp.niter + kp.maxlag + 1 <= FFT_MAXN) && kp.mode != 3;
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
@@ -3004,14 +3023,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             SeriesOut so;
             // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
             // bits whichever autocovariance path follows
-            if (acov && kp.method == 1) {
+            if (acov && fft_lds) {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_fft_phase(kp, YZ, smem);
             } else if (zfast || !acov) {
                 so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, acov, smem) : series_z_phase<false>(kp, zb, nullptr, acov, smem);
+                if (acov) so.ess = fft_const_chain_nan(so.ess);
             } else {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_phase(kp, YZ, true, smem, true);
+                so.ess = fft_const_chain_nan(so.ess);
             }
             rb = (kp.mode == 1) ? 0.0 : so.rhat;
             if (acov) eb = so.ess;

@@ -169,10 +169,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     if (rq.need_et && D > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
+    // (FFTAutocovMethod beyond 8192 padded points: the same linear autocorrelation from lagged products, see the kernel)
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
-    if (fft && niter + maxlag + 1 > mdt_big::FFT_MAXN)
-        return fail(ctx, MDT_EUNSUPPORTED, "FFTAutocovMethod on the device needs draws/split_chains + maxlag + 1 <= 8192 "
-                                           "(the in-LDS transform); use AutocovMethod for longer chains");
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&

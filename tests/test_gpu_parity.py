@@ -231,8 +231,19 @@ def test_long_chain_shape(pkg, methods):
     want = co.bulk_tail(x)
     for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
         assert_close(a, b, RTOL64, nm)
-    with pytest.raises(NotImplementedError):  # the in-LDS FFT holds 8192 points; says so instead of guessing
-        pkg.ess(dev(x), kind="bulk", autocov_method=methods["fft"])
+    # FFTAutocovMethod beyond the in-LDS transform (8192 padded points): the same linear autocorrelation from
+    # lagged products; BASELINE config 3 forces this method
+    for kind in ("bulk", "tail", "basic"):
+        S, R = pkg.ess_rhat(dev(x), kind=kind, autocov_method=methods["fft"])
+        We, Wr = co.ess_rhat(x, kind=kind, autocov="fft")
+        assert_close(host(S), We, RTOL64, f"fft long {kind} ess")
+        assert_close(host(R), Wr, RTOL64, f"fft long {kind} rhat")
+    xc = x.copy()
+    xc[:50_000, 3, 0] = 0.25  # a constant split chain: 0/0 = NaN in the FFT method only (src/ess_rhat.jl:192)
+    S = pkg.ess(dev(xc), kind="basic", autocov_method=methods["fft"])
+    We, _ = co.ess_rhat(xc, kind="basic", autocov="fft")
+    assert np.isnan(host(S)[0]) and np.isnan(We[0])
+    assert_close(host(S), We, RTOL64, "fft long const chain")
 
 
 def test_long_slices_with_point_masses_and_nans(pkg):
