@@ -55,6 +55,12 @@ extern "C" {
 #define MDT_KIND_BULK 1
 #define MDT_KIND_TAIL 2
 #define MDT_KIND_RANK 3
+/* estimators of ess(x; kind = f) with an expectand proxy (src/ess_rhat.jl:291-297, 626-659); mdt_ess_rhat with
+ * outputs == MDT_OUT_ESS only.  MDT_KIND_QUANTILE is Base.Fix2(Statistics.quantile, p) with p = args->tail_prob. */
+#define MDT_KIND_MEDIAN 4   /* Statistics.median: 1[x <= median(x)]            (:630-639) */
+#define MDT_KIND_STD 5      /* Statistics.std: (x - mean(x))^2                 (:640-642) */
+#define MDT_KIND_MAD 6      /* StatsBase.mad: median proxy of |x - median(x)|  (:643-646) */
+#define MDT_KIND_QUANTILE 7 /* Fix2(quantile, p): 1[x <= quantile(x, p)]       (:647-659) */
 /* outputs bitmask: ess() asks for ESS only, rhat() for RHAT only, ess_rhat() for both */
 #define MDT_OUT_ESS 1
 #define MDT_OUT_RHAT 2
@@ -117,6 +123,10 @@ int mdt_rhat_nested(mdt_ctx* ctx, const mdt_args* args, const void* x, const int
 /* mcse(x; kind=Statistics.mean) -- replaces src/mcse.jl:45-51 (basic ESS, then pooled corrected
  * std over all draws and chains divided by sqrt(ESS)).  args->kind is ignored. */
 int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
+
+/* mcse(x; kind=Statistics.std) -- replaces src/mcse.jl:52-65 (ESS of the proxy (x - mean)^2, then the delta
+ * method sqrt((E[mu4]/E[var] - E[var]) / S) / 2).  args->kind is ignored. */
+int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
 /*
  * Stage output for parity checks: _rank_normalize (src/utils.jl:169-184) of x (or, with

@@ -61,6 +61,8 @@ function _check(rc::Cint)
 end
 
 const _KIND = Dict(:basic => 0, :bulk => 1, :tail => 2, :rank => 3)
+# estimators with an expectand proxy (src/ess_rhat.jl:626-659): MDT_KIND_MEDIAN / STD / MAD / QUANTILE
+const _EST = Dict(:median => 4, :std => 5, :mad => 6, :quantile => 7)
 
 # (draws, chains, params...) -> (T, dense 3-d array) exactly like src/utils.jl:197-215
 function _params_array(x::AbstractArray)
@@ -73,7 +75,7 @@ _maybescalar(x::AbstractArray{<:Any,0}) = x[]
 _maybescalar(x::AbstractArray) = x
 _out(x, v) = _maybescalar(reshape(v, size(x)[3:end]...))
 
-function _ess_rhat(x, kind::Symbol, outputs; relative::Bool=false,
+function _ess_rhat(x, kind::Symbol, outputs; kindcode::Int=_KIND[kind], relative::Bool=false,
                    autocov_method::AbstractAutocovMethod=AutocovMethod(), split_chains::Int=2,
                    maxlag::Int=250, tail_prob::Real=1//10)
     T, x3 = _params_array(x)
@@ -82,7 +84,7 @@ function _ess_rhat(x, kind::Symbol, outputs; relative::Bool=false,
     (outputs & 1) != 0 && !(niter > 4) &&
         @warn "number of draws after splitting must be >4 but is $niter. ESS cannot be computed."
     S = Vector{T}(undef, P); R = Vector{T}(undef, P)
-    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, _KIND[kind], outputs, _code(autocov_method),
+    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, kindcode, outputs, _code(autocov_method),
                 split_chains, relative, 1, maxlag, Float64(tail_prob), C_NULL)
     GC.@preserve x3 S R begin
         _check(ccall((:mdt_ess_rhat, libmdt), Cint,
@@ -95,6 +97,13 @@ end
 
 function ess(x::AbstractArray{<:Real}; kind=:bulk, kwargs...)
     kind === Statistics.mean && return first(_ess_rhat(x, :basic, 1; kwargs...))  # src/ess_rhat.jl:629
+    # the other estimators with a proxy (src/ess_rhat.jl:630-659); the probability of a quantile travels in tail_prob
+    kind === Statistics.median && return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:median], kwargs...))
+    kind === Statistics.std && return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:std], kwargs...))
+    nameof(kind isa Function ? kind : typeof(kind)) === :mad &&  # StatsBase.mad (not a dependency of this shim)
+        return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:mad], kwargs...))
+    kind isa Base.Fix2{typeof(Statistics.quantile),<:Real} &&
+        return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:quantile], kwargs..., tail_prob=kind.x))
     kind isa Symbol && haskey(_KIND, kind) && kind !== :rank ||
         throw(ArgumentError("the `kind` `$kind` is not supported by `ess`"))
     return first(_ess_rhat(x, kind, 1; kwargs...))
@@ -133,13 +142,18 @@ end
 
 function mcse(x::AbstractArray{<:Real}; kind=Statistics.mean, autocov_method=AutocovMethod(),
               split_chains::Int=2, maxlag::Int=250)
-    kind === Statistics.mean || throw(ArgumentError("only kind=mean is on the device path"))
+    kind === Statistics.mean || kind === Statistics.std ||
+        throw(ArgumentError("only kind=mean and kind=std are on the device path"))  # src/mcse.jl:45-65
     T, x3 = _params_array(x)
     D, C, P = size(x3)
     out = Vector{T}(undef, P)
     a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL)
     GC.@preserve x3 out begin
-        _check(ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
+        if kind === Statistics.mean
+            _check(ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
+        else
+            _check(ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
+        end
     end
     return _out(x, out)
 end

@@ -11,6 +11,7 @@ from .api import (  # noqa: F401
     BDAAutocovMethod,
     ESSRhat,
     FFTAutocovMethod,
+    Quantile,
     bulk_tail,
     ess,
     ess_rhat,

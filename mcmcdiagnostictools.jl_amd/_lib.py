@@ -12,12 +12,12 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libmdt_hip.so")
 MDT_OK, MDT_EARG, MDT_EDOMAIN, MDT_EDIM, MDT_ERUNTIME, MDT_ENOMEM, MDT_EUNSUPPORTED = range(7)
 MDT_F64, MDT_F32 = 0, 1
 MDT_HOST, MDT_DEVICE = 0, 1
-KIND = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3}
+KIND = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3, "median": 4, "std": 5, "mad": 6, "quantile": 7}
 OUT_ESS, OUT_RHAT = 1, 2
 
 # every symbol include/mdt_hip.h declares
 SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_destroy", "mdt_last_error", "mdt_ess_rhat",
-           "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_rank_normalize",
+           "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_rank_normalize",
            "mdt_debug_phase_cycles")
 
 
@@ -79,6 +79,7 @@ def load():
         lib.mdt_bulk_tail.argtypes = [vp, ap, vp, vp, vp, vp, vp]
         lib.mdt_rhat_nested.argtypes = [vp, ap, vp, vp, i32, i32, vp]
         lib.mdt_mcse_mean.argtypes = [vp, ap, vp, vp]
+        lib.mdt_mcse_std.argtypes = [vp, ap, vp, vp]
         lib.mdt_rank_normalize.argtypes = [vp, ap, vp, i32, vp, vp]
         lib.mdt_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), i32]
         _ = i64

@@ -66,7 +66,34 @@ def _norm_kind(kind):
 
 def _is_mean(f):
     return f is np.mean or f is statistics.mean or f is statistics.fmean or (
-        torch is not None and f is torch.mean) or f == "mean"
+        torch is not None and f is torch.mean) or (isinstance(f, str) and f == "mean")
+
+
+class Quantile:
+    """The estimator `Base.Fix2(Statistics.quantile, p)` of the reference (src/ess_rhat.jl:647): `ess(x, kind=Quantile(0.25))`."""
+
+    def __init__(self, p):
+        self.p = float(p)
+
+    def __repr__(self):
+        return f"Quantile({self.p})"
+
+
+def _estimator(kind):
+    """estimator -> (C-ABI kind name, probability) for the estimators with an expectand proxy, else None"""
+    if isinstance(kind, Quantile):
+        return "quantile", kind.p
+    if isinstance(kind, tuple) and len(kind) == 2 and kind[0] in ("quantile", np.quantile):
+        return "quantile", float(kind[1])
+    if kind is np.median or kind is statistics.median or (torch is not None and kind is torch.median) or (
+            isinstance(kind, str) and kind == "median"):
+        return "median", 0.5
+    if kind is np.std or kind is statistics.stdev or (torch is not None and kind is torch.std) or (
+            isinstance(kind, str) and kind == "std"):
+        return "std", 0.5
+    if (isinstance(kind, str) and kind == "mad") or getattr(kind, "__name__", "") == "median_abs_deviation":
+        return "mad", 0.5
+    return None
 
 
 class _Prepared:
@@ -206,21 +233,24 @@ def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_m
 
 
 def ess(samples, *, kind="bulk", **kwargs):
-    """Effective sample size (src/ess_rhat.jl:276-311).  `kind` is "bulk", "tail", "basic" or an
-    estimator; of the estimators only the mean proxy (`numpy.mean`) is on the device path
-    (src/ess_rhat.jl:629), the others are listed as next in SURVEY.md §8f."""
+    """Effective sample size (src/ess_rhat.jl:276-311).  `kind` is "bulk", "tail", "basic" or an estimator
+    with an expectand proxy (src/ess_rhat.jl:626-659): mean (`numpy.mean`, "mean"), median (`numpy.median`,
+    "median"), std (`numpy.std`, "std"), mad ("mad", `scipy.stats.median_abs_deviation`) or `Quantile(p)`."""
     kind = _norm_kind(kind)
-    if kind in ("bulk", "tail", "basic"):
+    if isinstance(kind, str) and kind in ("bulk", "tail", "basic"):
         pr, e, _ = _call_ess_rhat(samples, kind, True, False, **kwargs)
         return _finish(pr, e)
-    if isinstance(kind, str):
-        raise ArgumentError(f"the `kind` `{kind}` is not supported by `ess`")
     if _is_mean(kind):
         kwargs.pop("tail_prob", None)
         pr, e, _ = _call_ess_rhat(samples, "basic", True, False, **kwargs)
         return _finish(pr, e)
-    if kind in (np.median, np.std, statistics.median):
-        raise NotImplementedError(f"the estimator {kind} is not on the device path yet (SURVEY.md §8f)")
+    est = _estimator(kind)
+    if est is not None:
+        kwargs.pop("tail_prob", None)
+        pr, e, _ = _call_ess_rhat(samples, est[0], True, False, tail_prob=est[1], **kwargs)
+        return _finish(pr, e)
+    if isinstance(kind, str):
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `ess`")
     raise ArgumentError(f"the estimator {kind} is not yet supported by `ess`")
 
 
@@ -301,9 +331,11 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
 
 
 def mcse(samples, *, kind=np.mean, **kwargs):
-    """Monte Carlo standard error; only kind=mean is on the device path (src/mcse.jl:45-51)."""
-    if not _is_mean(kind):
-        raise NotImplementedError("only mcse(kind=mean) is on the device path (SURVEY.md §8f)")
+    """Monte Carlo standard error for kind = mean (src/mcse.jl:45-51) or std (:52-65); the quantile / median
+    variants (Beta inverse CDF + order statistics, :66-118) and the SBM fallback are not on the device path."""
+    est = None if _is_mean(kind) else _estimator(kind)
+    if not _is_mean(kind) and (est is None or est[0] != "std"):
+        raise NotImplementedError("only mcse(kind=mean) and mcse(kind=std) are on the device path (SURVEY.md §8f)")
     split_chains = _check_int("split_chains", kwargs.pop("split_chains", 2))
     maxlag = _check_int("maxlag", kwargs.pop("maxlag", 250))
     autocov = _autocov_code(kwargs.pop("autocov_method", AutocovMethod()))
@@ -316,7 +348,8 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     if pr.P > 0:
         h = _lib.ctx(pr.device_index)
         a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
-        rc = _lib.load().mdt_mcse_mean(h, ctypes.byref(a), pr.ptr, _optr(out))
+        fn = _lib.load().mdt_mcse_mean if est is None else _lib.load().mdt_mcse_std
+        rc = fn(h, ctypes.byref(a), pr.ptr, _optr(out))
         _lib.check(rc, h)
     return _finish(pr, out)
 

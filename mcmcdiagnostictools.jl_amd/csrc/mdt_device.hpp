@@ -116,6 +116,7 @@ struct KP {
     int ess_ok;                 // niter > 4
     int relative;
     int fold;                   // rank_normalize stage: rank |x - median| instead of x
+    int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
@@ -223,6 +224,17 @@ struct SerX {          // series = raw draws of chain c
     long long D;
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); D = uni(D); }
     __device__ __forceinline__ double operator()(int c, long long row) const { return (double)xp[(long long)c * D + row]; }
+};
+template <typename T>
+struct SerSq {         // series = (x - mean)^2 evaluated in T: the expectand proxy of std (src/ess_rhat.jl:640-642)
+    const MDT_GA T* xp;
+    long long D;
+    T mu;
+    __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); D = uni(D); mu = uni(mu); }
+    __device__ __forceinline__ double operator()(int c, long long row) const {
+        const T d = (T)(xp[(long long)c * D + row] - mu);
+        return (double)(T)(d * d);
+    }
 };
 struct SerZ {          // series = normal scores, already in time order in the per-workgroup scratch
     const MDT_GA double* z;
@@ -1180,7 +1192,8 @@ struct SplitIter {
 // written at all: the pickup of every round adds its members to exact fixed-point sums per split chain and
 // mean_j[] / var_j[] hold the final means and variances (shift 0; a chain whose scores are all the same
 // bits gets variance exactly 0, as the reference's centred sum does).
-// out_req: 0 time order, 1 segment order if possible, 2 moments only if possible.
+// out_req: 0 time order, 1 segment order if possible, 2 moments only if possible, 4 nothing but the order
+// statistics (rounds that hold none of them are skipped altogether; returns 1, zout untouched).
 template <class VG>
 MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* smem, double* zout_, unsigned* esbuf_,
                            unsigned short* kbuf_, double* xsbuf_, unsigned short* ksbuf_, int ntgt_, int store_r2_, int out_req_) {
@@ -1229,7 +1242,8 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     const unsigned uD = (unsigned)kp.D, uniter = (unsigned)kp.niter, urem = (unsigned)kp.rem, us = (unsigned)kp.s, um = (unsigned)kp.m;
     // split-chain slots per class in the histogram: m real ones + 1 for dropped rows
     const int out_req = uni(out_req_);
-    const int NJ = (out_req && kp.m + 1 <= 64) ? kp.m + 1 : 1; // slots the elements are tagged with
+    const bool noout = out_req == 4;
+    const int NJ = ((out_req == 1 || out_req == 2) && kp.m + 1 <= 64) ? kp.m + 1 : 1; // slots the elements are tagged with
     const int NJc = (out_req == 1 && (NJ * NCLS + 1) * 4 <= CC2_BYTES) ? NJ : 1; // slots the class histogram is kept for (segment sizes)
     const bool momout = out_req == 2 && NJ > 1;
     // moments-only view of the mean_j / var_j bytes while the rounds run (65 slots each)
@@ -1498,6 +1512,11 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         const int clo = rlo[r], chi = rhi[r];
         const unsigned base = rbase[r];
         const unsigned cnt = rcur[r];
+        if (noout) { // order statistics only: a round that holds none of them is not ranked at all
+            bool any = false;
+            for (int t = 0; t < ntgt; ++t) any = any || (tpos[t] - base < cnt);
+            if (!any) continue;
+        }
         int F2 = NBL / (chi - clo);
         F2 = F2 > 4096 ? 4096 : F2;
         const double f2m1 = (double)(F2 - 1);
@@ -1654,7 +1673,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                     if (tpos[t] - less < eq) ostat[t] = v;
             }
         }
-        {
+        if (!noout) {
             double zz[DENSE_ITQ];
 #pragma unroll
             for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
@@ -1744,7 +1763,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 unsigned less = nn;
                 for (long long i = 0; i < e; ++i) less += ((kbuf[i] & TAG_CLS) == CLS_NAN) ? 1u : 0u;
                 const unsigned r2 = 2u * less + 2u;
-                zout[e] = store_r2 ? (double)r2 : ztab[r2];
+                if (!noout) zout[e] = store_r2 ? (double)r2 : ztab[r2];
                 for (int t = 0; t < ntgt; ++t)
                     if (tpos[t] == less) ostat[t] = __builtin_nan("");
             }
@@ -2466,9 +2485,11 @@ __device__ __forceinline__ unsigned long long bits_at(const unsigned long long* 
 // ESS of the two indicators 1[x <= q_lo], 1[x <= q_hi] (src/ess_rhat.jl:301-311): returns
 // min(ess_lo, ess_hi) with Julia's NaN-propagating min.
 template <typename T>
-MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, double qhi_, unsigned char* smem) {
+MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, double qhi_, unsigned char* smem, int fold_ = 0, T med_ = (T)0) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     const double qlo = uni(qlo_), qhi = uni(qhi_);
+    const int fold = uni(fold_); // indicators of |x - med| (mad proxy, src/ess_rhat.jl:643-646) instead of x
+    const T med = uni(med_);
     const MDT_GA T* xp = uniptr_g(xp_);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* scal = (double*)(smem + OFF_SCAL);
@@ -2496,7 +2517,8 @@ MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, doubl
             // raw ballots of chain c
             for (int wi = w; wi < nwD; wi += NWAVE) {
                 const long long t = ((long long)wi << 6) + lane;
-                const T v = (t < D) ? xp[(long long)c * D + t] : (T)0;
+                T v = (t < D) ? xp[(long long)c * D + t] : (T)0;
+                if (fold) { const T d = (T)(v - med); v = d < (T)0 ? -d : d; }
                 const unsigned long long b0 = __ballot(t < D && v <= tq[0]);
                 const unsigned long long b1 = __ballot(t < D && v <= tq[1]);
                 if (lane == 0) { bits[wi] = b0; bits[BITW + wi] = b1; }
@@ -2620,9 +2642,11 @@ constexpr int LDS_IND2_END = OFF_ICNT2 + (4 * NLAGTAB + 2 * MAXM) * 8;
 static_assert(LDS_IND2_END <= LDS_BYTES, "indicator (register) view exceeds the LDS carve");
 
 template <typename T>
-MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T qhi_, unsigned char* smem) {
+MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T qhi_, unsigned char* smem, int fold_ = 0, T med_ = (T)0) {
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     const T qlo = uni(qlo_), qhi = uni(qhi_);
+    const int fold = uni(fold_);
+    const T med = uni(med_);
     const MDT_GA T* xp = uniptr_g(xp_);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* scal = (double*)(smem + OFF_SCAL);
@@ -2644,6 +2668,10 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
         T xb[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) { const long long e = (j0 + u) * NT + tid; xb[u] = (e < n) ? xp[e] : (T)0; }
+        if (fold) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { const T d = (T)(xb[u] - med); xb[u] = d < (T)0 ? -d : d; }
+        }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const long long e = (j0 + u) * NT + tid;
@@ -2907,16 +2935,47 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             return anyc ? nan : ess;
         };
 
-        if (kp.basic && kp.mode != 3) {
-            const bool acov = kp.need_eb && kp.ess_ok;
+        auto basic_ess_rhat = [&](auto Y, bool acov) -> SeriesOut { // _ess_rhat_basic! on the series Y
             SeriesOut so;
             if (acov && fft_lds) {
-                (void)series_phase(kp, YX, false, smem); // moments -> mean_j / var_j / R-hat
-                so = series_fft_phase(kp, YX, smem);
+                (void)series_phase(kp, Y, false, smem); // moments -> mean_j / var_j / R-hat
+                so = series_fft_phase(kp, Y, smem);
             } else {
-                so = series_phase(kp, YX, acov, smem);
+                so = series_phase(kp, Y, acov, smem);
                 if (acov) so.ess = fft_const_chain_nan(so.ess);
             }
+            return so;
+        };
+
+        if (kp.est == 5) { // ess(kind = std) / mcse(kind = std): basic ESS of (x - mean)^2 (src/ess_rhat.jl:640-642)
+            double loc = 0.0;
+            for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
+            const T muT = (T)(wg_sum(loc, red) / (double)n);
+            const SerSq<T> YS{(const MDT_GA T*)xp, D, muT};
+            const SeriesOut so = basic_ess_rhat(YS, kp.ess_ok != 0);
+            const double ess = kp.ess_ok ? so.ess : nan;
+            if (kp.mode == 4) {
+                // src/mcse.jl:52-65: sqrt((E[mu4] / E[var] - E[var]) / S) / 2, E[var] = mean(proxy), E[mu4] = mean(proxy^2)
+                double l1 = 0.0, l2 = 0.0;
+                for (long long e = tid; e < n; e += NT) {
+                    const T d = (T)(xp[e] - muT);
+                    const double y = (double)(T)(d * d);
+                    l1 += y;
+                    l2 = fma(y, y, l2);
+                }
+                const double mv = wg_sum(l1, red) / (double)n, m4 = wg_sum(l2, red) / (double)n;
+                if (tid == 0) store_out<T>(kp.out_eb, p, sqrt((m4 / mv - mv) / ess) / 2.0);
+            } else if (tid == 0) {
+                store_out<T>(kp.out_eb, p, ess);
+            }
+            __syncthreads();
+            MDT_PROF_MARK(PH_SERB);
+            continue;
+        }
+
+        if (kp.basic && kp.mode != 3) {
+            const bool acov = kp.need_eb && kp.ess_ok;
+            const SeriesOut so = basic_ess_rhat(YX, acov);
             double ess = acov ? so.ess : nan;
             if (kp.mode == 1) {
                 if (tid == 0) store_out<T>(kp.out_rb, p, nested_combine());
@@ -2940,8 +2999,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
 
 
         // ---- ranking of x; capture median / quantile neighbours on the way
-        const bool need_med = kp.need_rt || (kp.mode == 3 && kp.fold);
-        const bool need_q = kp.need_et && kp.ess_ok;
+        const bool est_ind = kp.est == 4 || kp.est == 6 || kp.est == 7; // estimators whose proxy is an indicator
+        const bool need_med = kp.need_rt || (kp.mode == 3 && kp.fold) || ((kp.est == 4 || kp.est == 6) && kp.ess_ok);
+        const bool need_q = (kp.need_et || kp.est == 7) && kp.ess_ok;
         int ntgt = 0;
         if (tid == 0) {
             int t = 0;
@@ -2962,7 +3022,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
-                rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3, seg_req && (kp.need_eb || kp.need_rb));
+                rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3,
+                                  est_ind ? 4 : ((seg_req && (kp.need_eb || kp.need_rb)) ? 1 : 0));
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
@@ -2996,18 +3057,45 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         __syncthreads();
         const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
-        auto rank_folded = [&]() {
+        auto rank_folded = [&](int nt, int out_req) {
             rk = 0;
             if (kp.rank_variant == 2) {
-                rk = rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3, kp.mode != 3 ? 2 : 0);
-                if (!rk) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
-            } else if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, 0, kp.mode == 3);
-            else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, 0, kp.mode == 3);
-            else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, 0, kp.mode == 3);
+                rk = rank_phase_q(kp, VF, n, smem, zb, pbuf, bb, xs, bs, nt, kp.mode == 3, out_req);
+                if (!rk) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, nt, kp.mode == 3);
+            } else if (kp.rank_variant == 1) rank_phase_p(kp, VF, n, smem, zb, pbuf, bb, xs, bs, nt, kp.mode == 3);
+            else if (pos16) rank_phase_b<unsigned short>(kp, VF, n, smem, zb, (unsigned short*)pbuf, bb, nt, kp.mode == 3);
+            else rank_phase_b<unsigned>(kp, VF, n, smem, zb, pbuf, bb, nt, kp.mode == 3);
         };
 
+        if (est_ind) {
+            // ess(kind = median | mad | quantile(p)): basic ESS of an indicator (src/ess_rhat.jl:630-659); both
+            // thresholds of the indicator phase are the same here
+            double ee = nan;
+            if (kp.ess_ok) {
+                T thr = (kp.est == 7) ? qloT : medT;
+                int fold = 0;
+                if (kp.est == 6 && !has_nan) { // median of |x - median|: the folded ranking, order statistics only
+                    if (tid == 0) { tpos[0] = (unsigned)((n - 1) / 2); tpos[1] = (unsigned)(n / 2); }
+                    __syncthreads();
+                    rank_folded(2, 4);
+                    const T a = (T)ostat[0], b = (T)ostat[1];
+                    thr = (n & 1) ? a : (T)(a / (T)2 + b / (T)2);
+                    fold = 1;
+                    __syncthreads();
+                }
+                if (kp.est == 7 && thr != thr) { if (tid == 0) atomicOr(kp.status, 2); } // Statistics.quantile throws on NaN
+                else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
+                    ee = indicator_phase_pooled<T>(kp, xp, thr, thr, smem, fold, medT);
+                else ee = indicator_phase<T>(kp, xp, (double)thr, (double)thr, smem, fold, medT);
+            }
+            if (tid == 0) store_out<T>(kp.out_eb, p, ee);
+            __syncthreads();
+            MDT_PROF_MARK(PH_IND);
+            continue;
+        }
+
         if (kp.mode == 3) { // stage output: _rank_normalize of x or of the folded x
-            if (kp.fold) rank_folded();
+            if (kp.fold) rank_folded(0, 0);
             for (long long e = tid; e < n; e += NT) {
                 const double r = zb[e]; // doubled rank (store_r2 mode)
                 if (kp.rank_out) kp.rank_out[p * n + e] = r * 0.5;
@@ -3045,7 +3133,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
-            rank_folded();
+            rank_folded(0, kp.mode != 3 ? 2 : 0);
             MDT_PROF_MARK(PH_RANKF);
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
             // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores

@@ -137,6 +137,7 @@ struct Req {
     void* out_rrank = nullptr;
     double* rank_out = nullptr; void* z_out = nullptr;
     int fold = 0;
+    int est = 0; // ess(kind = estimator): MDT_KIND_MEDIAN .. MDT_KIND_QUANTILE
     const int32_t* chain_inds = nullptr; int K = 0, S = 0;
     int want_ess = 0; // ESS of some kind is requested (drives the maxlag domain check)
 };
@@ -163,12 +164,15 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         maxlag = 1;
     }
     if (!(a->tail_prob > 0.0 && a->tail_prob < 1.0) && rq.need_et) return fail(ctx, MDT_EARG, "tail_prob must be in (0, 1)");
+    if (rq.est == MDT_KIND_QUANTILE && !(a->tail_prob >= 0.0 && a->tail_prob <= 1.0))
+        return fail(ctx, MDT_EARG, "quantile probability must be in [0, 1]"); // Statistics.quantile
     // engine limits
     static_assert(mdt_big::MAXM == mdt_small::MAXM, "one limit for both geometries");
     if (m > mdt_big::MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
-    if (rq.need_et && D > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for tail ESS");
+    const bool indicators = rq.need_et || rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE;
+    if (indicators && D > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for indicator ESS (tail, median, mad, quantile)");
     // (FFTAutocovMethod beyond 8192 padded points: the same linear autocorrelation from lagged products, see the kernel)
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
@@ -239,7 +243,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.x = dx;
     kp.D = D; kp.C = C; kp.P = P; kp.n = n;
     kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
-    kp.mode = rq.mode; kp.basic = rq.basic;
+    kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est;
     kp.need_eb = rq.need_eb; kp.need_rb = rq.need_rb; kp.need_et = rq.need_et; kp.need_rt = rq.need_rt;
     kp.method = a->autocov; kp.ess_ok = ess_ok; kp.relative = a->relative ? 1 : 0; kp.fold = rq.fold;
     kp.maxlag = maxlag;
@@ -252,7 +256,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     for (int i = 0; i < 2; ++i) {
         long long j; double g;
         if (f32) {
-            const float p = (i == 0) ? (float)(a->tail_prob / 2) : (float)(1 - a->tail_prob / 2);
+            const float p = (rq.est == MDT_KIND_QUANTILE) ? (float)a->tail_prob : ((i == 0) ? (float)(a->tail_prob / 2) : (float)(1 - a->tail_prob / 2));
             const float aleph = fmaf((float)n, p, 1.0f - p);
             j = (long long)aleph;
             if (j < 1) j = 1;
@@ -261,7 +265,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
             gg = gg < 0 ? 0 : (gg > 1 ? 1 : gg);
             g = (double)gg;
         } else {
-            const double p = (i == 0) ? (a->tail_prob / 2) : (1 - a->tail_prob / 2);
+            const double p = (rq.est == MDT_KIND_QUANTILE) ? a->tail_prob : ((i == 0) ? (a->tail_prob / 2) : (1 - a->tail_prob / 2));
             const double aleph = fma((double)n, p, 1.0 - p);
             j = (long long)aleph;
             if (j < 1) j = 1;
@@ -419,6 +423,13 @@ int mdt_ess_rhat(mdt_ctx* ctx, const mdt_args* a, const void* x, void* ess_out, 
         rq.need_eb = want_ess; rq.need_rb = want_rhat; rq.need_rt = want_rhat;
         rq.out_eb = want_ess ? ess_out : nullptr; rq.out_rrank = want_rhat ? rhat_out : nullptr;
         break;
+    case MDT_KIND_MEDIAN: case MDT_KIND_STD: case MDT_KIND_MAD: case MDT_KIND_QUANTILE:
+        // ess(x; kind = estimator) through its expectand proxy (src/ess_rhat.jl:291-297, 626-659); rhat and
+        // ess_rhat take symbols only (:335-349, :438-455)
+        if (want_rhat) return fail(ctx, MDT_EARG, "estimator kinds are supported by `ess` only");
+        rq.est = a->kind; rq.out_eb = ess_out;
+        rq.basic = a->kind == MDT_KIND_STD; // no ranking for the std proxy
+        break;
     default:
         return fail(ctx, MDT_EARG, "the `kind` is not supported"); // src/ess_rhat.jl:286,347,453
     }
@@ -465,6 +476,14 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out
     if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
     Req rq;
     rq.mode = 2; rq.basic = 1; rq.need_eb = 1; rq.out_eb = mcse_out; rq.want_ess = 1;
+    return run(ctx, a, x, rq);
+}
+
+int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out) {
+    if (!ctx) return MDT_EARG;
+    if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
+    Req rq;
+    rq.mode = 4; rq.basic = 1; rq.est = MDT_KIND_STD; rq.out_eb = mcse_out; rq.want_ess = 1;
     return run(ctx, a, x, rq);
 }
 

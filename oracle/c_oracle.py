@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-KINDS = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3}
+KINDS = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3, "median": 4, "std": 5, "mad": 6, "quantile": 7}
 AUTOCOV = {"direct": 0, "fft": 1, "bda": 2}
 
 
@@ -134,6 +134,30 @@ def mcse_mean(x, autocov="direct", split_chains=2, maxlag=250, faithful=False):
     a = _args(x, "basic", autocov, split_chains, maxlag, False, 0.1)
     out = np.empty(x.shape[2], x.dtype)
     f = getattr(lib(), "mdt_oracle_mcse_mean" + _sfx(x.dtype, faithful))
+    rc = f(ctypes.byref(a), _ptr(x), _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def ess_estimator(x, estimator, prob=0.5, autocov="direct", split_chains=2, maxlag=250, relative=False,
+                  faithful=False):
+    """ess(x; kind=estimator) for 'median' | 'std' | 'mad' | 'quantile' (with `prob`), src/ess_rhat.jl:291-297"""
+    x = _as3d(x)
+    a = _args(x, estimator, autocov, split_chains, maxlag, relative, prob)
+    out = np.empty(x.shape[2], x.dtype)
+    f = getattr(lib(), "mdt_oracle_ess_rhat" + _sfx(x.dtype, faithful))
+    rc = f(ctypes.byref(a), _ptr(x), _ptr(out), None)
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
+def mcse_std(x, autocov="direct", split_chains=2, maxlag=250, faithful=False):
+    x = _as3d(x)
+    a = _args(x, "basic", autocov, split_chains, maxlag, False, 0.1)
+    out = np.empty(x.shape[2], x.dtype)
+    f = getattr(lib(), "mdt_oracle_mcse_std" + _sfx(x.dtype, faithful))
     rc = f(ctypes.byref(a), _ptr(x), _ptr(out))
     if rc:
         raise OracleError(rc)

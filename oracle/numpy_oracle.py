@@ -207,3 +207,39 @@ def mcse_mean(x, s=2, maxlag=250, method="direct"):
         with np.errstate(all="ignore"):
             out[p] = np.std(x[:, :, p], ddof=1) / np.sqrt(S)
     return out
+
+
+def ess_estimator(x, estimator, prob=0.5, method="direct", s=2, maxlag=250, relative=False):
+    """ess(x; kind=estimator) through the expectand proxies of src/ess_rhat.jl:626-659."""
+    x = np.asarray(x, dtype=np.float64)
+    P = x.shape[2]
+    out = np.empty(P)
+    for p in range(P):
+        xp = x[:, :, p]
+        if estimator == "median":
+            y = (xp <= np.median(xp)).astype(np.float64)
+        elif estimator == "std":
+            y = (xp - xp.mean()) ** 2
+        elif estimator == "mad":
+            f = fold(xp)
+            y = (f <= np.median(f)).astype(np.float64)
+        elif estimator == "quantile":
+            y = (xp <= quantile7(xp.ravel(order="F"), prob)).astype(np.float64)
+        else:
+            raise ValueError(estimator)
+        out[p], _ = ess_rhat_basic(y, s, maxlag, method, relative)
+    return out
+
+
+def mcse_std(x, s=2, maxlag=250, method="direct"):
+    """src/mcse.jl:52-65."""
+    x = np.asarray(x, dtype=np.float64)
+    P = x.shape[2]
+    out = np.empty(P)
+    for p in range(P):
+        y = (x[:, :, p] - x[:, :, p].mean()) ** 2
+        S, _ = ess_rhat_basic(y, s, maxlag, method, False)
+        mv, m4 = y.mean(), (y ** 2).mean()
+        with np.errstate(all="ignore"):
+            out[p] = np.sqrt((m4 / mv - mv) / S) / 2
+    return out

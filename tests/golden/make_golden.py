@@ -156,5 +156,43 @@ def main():
     print("wrote", len(cases), "fixtures to", OUT)
 
 
+ESTIMATORS = [("median", 0.5), ("std", 0.5), ("mad", 0.5), ("quantile", 0.25), ("quantile", 0.9)]
+
+
+def estimators():
+    """ess(x; kind = estimator) and mcse(x; kind = std) on the INPUTS of fixtures that
+    already exist (so those are not regenerated): est_<name>.npz, keys est|<estimator>|<p>|<method>|<s>."""
+    names = ["cfg1_randn_1000x4x10", "ar1_500x4x10", "ties_200x4x6", "odd_1001x3x3", "onechain_400x1x3",
+             "constant_100x3x2", "short_5x3x2", "special_50x2x3", "f32_300x4x6"]
+    n = 0
+    for name in names:
+        x = np.load(os.path.join(OUT, name + ".npz"))["x"]
+        f32 = x.dtype == np.float32
+        c = {}
+        for est, p in ESTIMATORS:
+            for m in (("direct",) if f32 else METHODS):
+                for s in ((2,) if f32 else (1, 2, 3)):
+                    key = f"est|{est}|{p}|{m}|{s}"
+                    try:
+                        e = co.ess_estimator(x, est, prob=p, autocov=m, split_chains=s)
+                    except co.OracleError:  # quantile of data with NaN throws (Statistics.quantile)
+                        c["err|" + key] = np.array([1])
+                        continue
+                    if not f32:
+                        agree(e, no.ess_estimator(x, est, prob=p, method=m, s=s), what=name + " " + key)
+                    c[key] = e
+        if not np.isnan(x).any():
+            c["mcse_std"] = co.mcse_std(x)
+            if not f32:
+                agree(c["mcse_std"], no.mcse_std(x), what=name + " mcse_std")
+        np.savez_compressed(os.path.join(OUT, "est_" + name + ".npz"), **c)
+        n += 1
+    print("wrote", n, "estimator fixtures to", OUT)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "estimators":
+        estimators()
+    else:
+        main()
+        estimators()

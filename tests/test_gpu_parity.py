@@ -326,3 +326,33 @@ def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
                 assert_close(a, b, 1e-12, "rhat_tail")
             else:
                 assert np.array_equal(a, b, equal_nan=True), (v, k)
+
+
+@pytest.mark.parametrize("name", golden_names(estimators=True))
+def test_estimator_kinds(pkg, methods, name):
+    """ess(x; kind = estimator) for the estimators with an expectand proxy and mcse(kind = std) against the
+    golden vectors"""
+    import warnings
+    g = load_golden(name)
+    x = load_golden(name[4:])["x"]
+    xd = dev(x)
+    tol = RTOL64 if x.dtype == np.float64 else 1e-6
+    kinds = {"median": np.median, "std": np.std, "mad": "mad"}
+    for k, want in g.items():
+        if not (k.startswith("est|") or k.startswith("err|")):
+            continue
+        parts = k.split("|")
+        est, p, m, s = parts[-4:]
+        kind = pkg.Quantile(float(p)) if est == "quantile" else kinds[est]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if k.startswith("err|"):
+                with pytest.raises(pkg.ArgumentError):
+                    pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=int(s))
+            else:
+                got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=int(s))
+                assert_close(host(got), want, tol, f"{name} {k}")
+    if "mcse_std" in g:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert_close(host(pkg.mcse(xd, kind=np.std)), g["mcse_std"], tol, name + " mcse_std")

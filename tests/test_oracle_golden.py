@@ -92,3 +92,26 @@ def test_f32_golden():
             assert_close(r, g[f"rhat|{kind}|{m}|2|250"], 1e-6)
             # the Float32-faithful variant stays within Float32 noise of the f64-internal one
             assert_close(g[f"rhatF|{kind}|{m}|2|250"], r, 1e-3)
+
+
+@pytest.mark.parametrize("name", golden_names(estimators=True))
+def test_estimator_golden(name):
+    """ess(x; kind = median | std | mad | quantile(p)) and mcse(x; kind = std) (src/ess_rhat.jl:626-659,
+    src/mcse.jl:52-65): the C oracle reproduces the committed vectors (minted where C and numpy agreed)"""
+    from oracle import c_oracle as co
+    g = load_golden(name)
+    x = load_golden(name[4:])["x"]
+    n = 0
+    for k, want in g.items():
+        if k.startswith("est|"):
+            _, est, p, m, s = k.split("|")
+            got = co.ess_estimator(x, est, prob=float(p), autocov=m, split_chains=int(s))
+            assert_close(got, want, 1e-12, f"{name} {k}")
+            n += 1
+        elif k.startswith("err|"):
+            _, _, est, p, m, s = k.split("|")
+            with pytest.raises(co.OracleError):
+                co.ess_estimator(x, est, prob=float(p), autocov=m, split_chains=int(s))
+    if "mcse_std" in g:
+        assert_close(co.mcse_std(x), g["mcse_std"], 1e-12, name + " mcse_std")
+    assert n > 0
