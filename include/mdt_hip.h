@@ -129,6 +129,14 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_
 int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
 /*
+ * Storage-order helper: MCMCChains keeps (iterations, parameters, chains); every entry
+ * point above wants (draws, chains, params).  One coalesced device pass, out of place:
+ * x_dpc[d + draws*(p + params*c)] -> x_dcp[d + draws*(c + chains*p)], instead of a host-side permutedims.
+ * args: draws, chains, params, dtype, stream, sync; location must be MDT_DEVICE.
+ */
+int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* args, const void* x_dpc, void* x_dcp);
+
+/*
  * Stage output for parity checks: _rank_normalize (src/utils.jl:169-184) of x (or, with
  * fold != 0, of _fold_around_median(x), :148-158).  rank_out: [draws*chains*params] float64
  * tied ranks (StatsBase.tiedrank) or NULL; z_out: same length, dtype, normal scores, or NULL.

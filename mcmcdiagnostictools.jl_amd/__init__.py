@@ -15,6 +15,7 @@ from .api import (  # noqa: F401
     bulk_tail,
     ess,
     ess_rhat,
+    from_mcmcchains_layout,
     mcse,
     rank_normalize,
     rhat,

@@ -374,3 +374,25 @@ def rank_normalize(samples, *, fold=False, want_ranks=True):
         o3 = o3.permute(2, 1, 0) if pr.torch else np.transpose(o3, (2, 1, 0))
         return o3.reshape(pr.orig_shape)
     return back(ranks), back(z)
+
+
+def from_mcmcchains_layout(samples):
+    """(iterations, parameters, chains) device tensor, as MCMCChains stores it -> the (draws, chains, params)
+    view every function here takes, through ONE coalesced device pass (mdt_layout_from_dpc) instead of a
+    host-side permutedims.  The result is a zero-copy view of a (params, chains, draws)-contiguous buffer."""
+    if torch is None or not isinstance(samples, torch.Tensor) or not samples.is_cuda:
+        raise ArgumentError("from_mcmcchains_layout takes a CUDA tensor of shape (iterations, parameters, chains)")
+    if samples.dim() != 3 or samples.dtype not in (torch.float32, torch.float64):
+        raise ArgumentError("expected a 3-d float32/float64 tensor")
+    D, P, C = samples.shape
+    src = samples.permute(2, 1, 0).contiguous()  # memory = Julia's column-major (D, P, C): no-op if it already is
+    out = torch.empty((P, C, D), dtype=samples.dtype, device=samples.device)
+    pr = _Prepared()
+    pr.D, pr.C, pr.P = D, C, P
+    pr.f32 = samples.dtype == torch.float32
+    pr.dev, pr.buf = True, out
+    h = _lib.ctx(samples.device.index or 0)
+    a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
+    rc = _lib.load().mdt_layout_from_dpc(h, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
+    _lib.check(rc, h)
+    return out.permute(2, 1, 0)

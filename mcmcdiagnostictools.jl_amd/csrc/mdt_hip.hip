@@ -74,6 +74,16 @@ struct mdt_ctx {
 
 namespace {
 
+// (draws, params, chains) -> (draws, chains, params): both sides are runs of `draws` contiguous values
+template <typename T>
+__global__ void permute_dpc_kernel(const T* __restrict__ in, T* __restrict__ out, long long D, long long C, long long P) {
+    const long long run = blockIdx.x; // = p + P * c in the source
+    const long long c = run / P, p = run - c * P;
+    const T* src = in + run * D;
+    T* dst = out + (c + C * p) * D;
+    for (long long d = threadIdx.x; d < D; d += blockDim.x) dst[d] = src[d];
+}
+
 constexpr unsigned KP_RING = 64;
 
 int fail(mdt_ctx* ctx, int code, const std::string& msg) {
@@ -485,6 +495,29 @@ int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out)
     Req rq;
     rq.mode = 4; rq.basic = 1; rq.est = MDT_KIND_STD; rq.out_eb = mcse_out; rq.want_ess = 1;
     return run(ctx, a, x, rq);
+}
+
+int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void* x_dcp) {
+    if (!ctx) return MDT_EARG;
+    if (!a || !x_dpc || !x_dcp) return fail(ctx, MDT_EARG, "NULL pointer");
+    if (a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "mdt_layout_from_dpc works on device buffers");
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    if (x_dpc == x_dcp) return fail(ctx, MDT_EARG, "the permutation is out of place");
+    const long long runs = a->chains * a->params;
+    if (runs == 0 || a->draws == 0) return MDT_OK;
+    if (runs > 2147483647LL) return fail(ctx, MDT_EUNSUPPORTED, "chains*params too large");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)a->stream;
+    if (a->dtype == MDT_F64)
+        hipLaunchKernelGGL(permute_dpc_kernel<double>, dim3((unsigned)runs), dim3(256), 0, st, (const double*)x_dpc, (double*)x_dcp,
+                           (long long)a->draws, (long long)a->chains, (long long)a->params);
+    else
+        hipLaunchKernelGGL(permute_dpc_kernel<float>, dim3((unsigned)runs), dim3(256), 0, st, (const float*)x_dpc, (float*)x_dcp,
+                           (long long)a->draws, (long long)a->chains, (long long)a->params);
+    HIP_TRY(hipGetLastError());
+    if (a->sync) HIP_TRY(hipStreamSynchronize(st));
+    return MDT_OK;
 }
 
 int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset) {

@@ -356,3 +356,19 @@ def test_estimator_kinds(pkg, methods, name):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             assert_close(host(pkg.mcse(xd, kind=np.std)), g["mcse_std"], tol, name + " mcse_std")
+
+
+def test_mcmcchains_storage_order(pkg):
+    """(iterations, parameters, chains) input -- MCMCChains storage -- through the device-side permutation"""
+    import torch
+    rng = np.random.default_rng(9)
+    for dt in (np.float64, np.float32):
+        x = rng.standard_normal((300, 4, 7)).astype(dt)            # (draws, chains, params)
+        t = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (0, 2, 1)))).cuda()  # (draws, params, chains)
+        v = pkg.from_mcmcchains_layout(t)
+        assert v.shape == (300, 4, 7)
+        assert np.array_equal(v.cpu().numpy(), x)
+        assert v.permute(2, 1, 0).is_contiguous()                  # the zero-copy layout of the engine
+        a = pkg.ess_rhat(v)
+        b = pkg.ess_rhat(dev(x))
+        assert np.array_equal(host(a.ess), host(b.ess)) and np.array_equal(host(a.rhat), host(b.rhat))
