@@ -128,6 +128,12 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_
  * method sqrt((E[mu4]/E[var] - E[var]) / S) / 2).  args->kind is ignored. */
 int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
+/* mcse(x; kind = Statistics.median) and mcse(x; kind = Base.Fix2(Statistics.quantile, p)) -- replaces
+ * src/mcse.jl:66-118: ESS of the indicator proxy (pass 1), the Beta(S p + 1, S (1-p) + 1) quadrature points on
+ * the host, two order statistics per parameter through a second, order-statistics-only ranking (pass 2).
+ * args->kind: MDT_KIND_MEDIAN or MDT_KIND_QUANTILE (p = args->tail_prob).  Synchronous between the passes. */
+int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
+
 /*
  * Storage-order helper: MCMCChains keeps (iterations, parameters, chains); every entry
  * point above wants (draws, chains, params).  One coalesced device pass, out of place:

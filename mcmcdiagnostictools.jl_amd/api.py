@@ -331,11 +331,12 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
 
 
 def mcse(samples, *, kind=np.mean, **kwargs):
-    """Monte Carlo standard error for kind = mean (src/mcse.jl:45-51) or std (:52-65); the quantile / median
-    variants (Beta inverse CDF + order statistics, :66-118) and the SBM fallback are not on the device path."""
+    """Monte Carlo standard error for kind = mean (src/mcse.jl:45-51), std (:52-65), median or Quantile(p)
+    (:66-118: Beta quadrature points + two order statistics); the SBM fallback for arbitrary estimators is
+    not on the device path."""
     est = None if _is_mean(kind) else _estimator(kind)
-    if not _is_mean(kind) and (est is None or est[0] != "std"):
-        raise NotImplementedError("only mcse(kind=mean) and mcse(kind=std) are on the device path (SURVEY.md §8f)")
+    if not _is_mean(kind) and (est is None or est[0] == "mad"):
+        raise NotImplementedError("mcse: kind must be mean, std, median or Quantile(p) on the device path (SURVEY.md §8f)")
     split_chains = _check_int("split_chains", kwargs.pop("split_chains", 2))
     maxlag = _check_int("maxlag", kwargs.pop("maxlag", 250))
     autocov = _autocov_code(kwargs.pop("autocov_method", AutocovMethod()))
@@ -347,8 +348,13 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     out = _new_out(pr)
     if pr.P > 0:
         h = _lib.ctx(pr.device_index)
-        a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
-        fn = _lib.load().mdt_mcse_mean if est is None else _lib.load().mdt_mcse_std
+        lib = _lib.load()
+        if est is None or est[0] == "std":
+            a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
+            fn = lib.mdt_mcse_mean if est is None else lib.mdt_mcse_std
+        else:
+            a = _args(pr, _lib.KIND[est[0]], 1, autocov, split_chains, maxlag, relative, est[1])
+            fn = lib.mdt_mcse_quantile
         rc = fn(h, ctypes.byref(a), pr.ptr, _optr(out))
         _lib.check(rc, h)
     return _finish(pr, out)

@@ -116,6 +116,7 @@ struct KP {
     int ess_ok;                 // niter > 4
     int relative;
     int fold;                   // rank_normalize stage: rank |x - median| instead of x
+    const unsigned int* tpos_arr; // mode 5: [P][2] zero-based sorted positions (l-1, u-1) per parameter; 0xFFFFFFFF: NaN
     int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
@@ -2860,7 +2861,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
     while (true) {
         if (tid == 0) *tick = atomicAdd(kp.status + 1, 1);
         __syncthreads();
-        const long long p = *tick;
+        const long long p = (long long)uni(*tick); // wave-uniform: every branch on p is a scalar branch
         __syncthreads();
         if (p >= kp.P) break;
         const T* __restrict__ xp = (const T*)kp.x + p * n;
@@ -2914,6 +2915,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 store_out<T>(kp.out_et, p, nan); store_out<T>(kp.out_rt, p, nan);
                 store_out<T>(kp.out_rrank, p, nan);
             }
+            __syncthreads(); // (an exit from the parameter without any barrier since the ticket wedged the workgroup)
             continue;
         }
 
@@ -3002,9 +3004,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const bool est_ind = kp.est == 4 || kp.est == 6 || kp.est == 7; // estimators whose proxy is an indicator
         const bool need_med = kp.need_rt || (kp.mode == 3 && kp.fold) || ((kp.est == 4 || kp.est == 6) && kp.ess_ok);
         const bool need_q = (kp.need_et || kp.est == 7) && kp.ess_ok;
+        if (kp.mode == 5 && kp.tpos_arr[2 * p] == 0xFFFFFFFFu) { // mcse quantile of a NaN ESS (src/mcse.jl:95-97)
+            if (tid == 0) store_out<T>(kp.out_eb, p, nan);
+            __syncthreads();
+            continue;
+        }
         int ntgt = 0;
         if (tid == 0) {
             int t = 0;
+            if (kp.mode == 5) { tpos[t++] = kp.tpos_arr[2 * p]; tpos[t++] = kp.tpos_arr[2 * p + 1]; }
             if (need_med) { tpos[t++] = (unsigned)((n - 1) / 2); tpos[t++] = (unsigned)(n / 2); }
             if (need_q) {
                 for (int i = 0; i < 2; ++i) {
@@ -3016,20 +3024,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         __syncthreads();
         ntgt = ((int*)(smem + OFF_INTS))[8];
-        const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold);
+        const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold) || kp.mode == 5;
         // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
         const bool seg_req = zfast && !(kp.method == 1 && kp.niter + kp.maxlag + 1 <= FFT_MAXN) && kp.mode != 3;
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
                 rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3,
-                                  est_ind ? 4 : ((seg_req && (kp.need_eb || kp.need_rb)) ? 1 : 0));
+                                  (est_ind || kp.mode == 5) ? 4 : ((seg_req && (kp.need_eb || kp.need_rb)) ? 1 : 0));
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
         }
         MDT_PROF_MARK(PH_RANKX);
+        if (kp.mode == 5) { // _mcse_quantile (src/mcse.jl:109-117): half the distance of two order statistics, in T
+            if (tid == 0) store_out<T>(kp.out_eb, p, (double)(T)(((T)ostat[1] - (T)ostat[0]) / (T)2));
+            __syncthreads();
+            continue;
+        }
 
         // order statistics -> median / quantiles, in T arithmetic like the reference
         T medT = (T)0, qloT = (T)0, qhiT = (T)0;

@@ -65,6 +65,10 @@ struct mdt_ctx {
     unsigned kp_next = 0;
     int* chain_inds = nullptr;
     int chain_inds_cap = 0;
+    // mcse quantile: ESS of the first pass and the order-statistic positions of the second
+    void* ess_tmp = nullptr;
+    unsigned int* tpos_arr = nullptr;
+    long long mq_cap = 0;
     // host staging
     void* stage_x = nullptr;
     size_t stage_x_cap = 0;
@@ -82,6 +86,54 @@ __global__ void permute_dpc_kernel(const T* __restrict__ in, T* __restrict__ out
     const T* src = in + run * D;
     T* dst = out + (c + C * p) * D;
     for (long long d = threadIdx.x; d < D; d += blockDim.x) dst[d] = src[d];
+}
+
+
+/* Regularised incomplete beta I_x(a, b) (continued fraction, modified Lentz) and its inverse (safeguarded
+ * Newton): StatsFuns.betainvcdf of src/mcse.jl:105-106.  Agrees with scipy.special.betaincinv to ~1e-11. */
+static double mdt_betacf(double a, double b, double x) {
+    const double qab = a + b, qap = a + 1.0, qam = a - 1.0, tiny = 1e-300;
+    double c = 1.0, d = 1.0 - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1.0 / d;
+    double h = d;
+    for (int m = 1; m < 2000; ++m) {
+        const double m2 = 2.0 * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d; h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1.0 / d;
+        const double de = d * c;
+        h *= de;
+        if (fabs(de - 1.0) < 1e-16) break;
+    }
+    return h;
+}
+static double mdt_ibeta(double a, double b, double x) {
+    if (x <= 0.0) return 0.0;
+    if (x >= 1.0) return 1.0;
+    const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
+    const double bt = exp(a * log(x) + b * log1p(-x) - lb);
+    if (x < (a + 1.0) / (a + b + 2.0)) return bt * mdt_betacf(a, b, x) / a;
+    return 1.0 - bt * mdt_betacf(b, a, 1.0 - x) / b;
+}
+static double mdt_betainvcdf(double a, double b, double p) {
+    double lo = 0.0, hi = 1.0, x = a / (a + b);
+    const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
+    for (int it = 0; it < 200; ++it) {
+        const double f = mdt_ibeta(a, b, x) - p;
+        if (f > 0.0) hi = x; else lo = x;
+        const double pdf = (x > 0.0 && x < 1.0) ? exp((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lb) : 0.0;
+        double xn = (pdf > 0.0) ? x - f / pdf : 0.5 * (lo + hi);
+        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+        if (fabs(xn - x) <= 1e-16 * x) { x = xn; break; }
+        x = xn;
+    }
+    return x;
 }
 
 constexpr unsigned KP_RING = 64;
@@ -149,6 +201,7 @@ struct Req {
     int fold = 0;
     int est = 0; // ess(kind = estimator): MDT_KIND_MEDIAN .. MDT_KIND_QUANTILE
     const int32_t* chain_inds = nullptr; int K = 0, S = 0;
+    const unsigned int* tpos_arr = nullptr; // mode 5
     int want_ess = 0; // ESS of some kind is requested (drives the maxlag domain check)
 };
 
@@ -301,6 +354,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
     kp.chain_inds = ctx->chain_inds; kp.K = rq.K; kp.S = rq.S;
+    kp.tpos_arr = rq.tpos_arr;
     kp.status = ctx->status;
     kp.prof = ctx->prof;
 
@@ -400,6 +454,8 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->prof) (void)hipFree(ctx->prof);
     if (ctx->kp_ring) (void)hipFree(ctx->kp_ring);
     if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
+    if (ctx->ess_tmp) (void)hipFree(ctx->ess_tmp);
+    if (ctx->tpos_arr) (void)hipFree(ctx->tpos_arr);
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     delete ctx;
@@ -495,6 +551,62 @@ int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out)
     Req rq;
     rq.mode = 4; rq.basic = 1; rq.est = MDT_KIND_STD; rq.out_eb = mcse_out; rq.want_ess = 1;
     return run(ctx, a, x, rq);
+}
+
+int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
+    if (a->kind != MDT_KIND_MEDIAN && a->kind != MDT_KIND_QUANTILE)
+        return fail(ctx, MDT_EARG, "mdt_mcse_quantile: kind must be MDT_KIND_MEDIAN or MDT_KIND_QUANTILE");
+    const long long P = a->params, n = a->draws * a->chains;
+    if (P <= 0) return run(ctx, a, x, Req());
+    const double p = (a->kind == MDT_KIND_MEDIAN) ? 0.5 : a->tail_prob;
+    const size_t ts = tsize(a->dtype);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)a->stream;
+    if (P > ctx->mq_cap) {
+        if (ctx->ess_tmp) (void)hipFree(ctx->ess_tmp);
+        if (ctx->tpos_arr) (void)hipFree(ctx->tpos_arr);
+        ctx->ess_tmp = nullptr; ctx->tpos_arr = nullptr; ctx->mq_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->ess_tmp, (size_t)P * 8));
+        HIP_TRY(hipMalloc((void**)&ctx->tpos_arr, (size_t)P * 2 * sizeof(unsigned int)));
+        ctx->mq_cap = P;
+    }
+    // pass 1: S = ess(x; kind = median | quantile(p))  (src/mcse.jl:73, 84)
+    std::string hostS((size_t)P * 8, '\0');
+    mdt_args a1 = *a;
+    a1.sync = 1;
+    Req r1;
+    r1.est = a->kind; r1.want_ess = 1;
+    r1.out_eb = (a->location == MDT_HOST) ? (void*)&hostS[0] : ctx->ess_tmp;
+    int rc = run(ctx, &a1, x, r1);
+    if (rc) return rc;
+    if (a->location == MDT_DEVICE) {
+        HIP_TRY(hipMemcpyAsync(&hostS[0], ctx->ess_tmp, (size_t)P * ts, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    // positions of the two quadrature points of the Beta error distribution (src/mcse.jl:93-108)
+    std::string hostT((size_t)P * 2 * sizeof(unsigned int), '\0');
+    unsigned int* tp = (unsigned int*)&hostT[0];
+    for (long long i = 0; i < P; ++i) {
+        const double S = (a->dtype == MDT_F32) ? (double)((const float*)&hostS[0])[i] : ((const double*)&hostS[0])[i];
+        if (S != S) { tp[2 * i] = 0xFFFFFFFFu; tp[2 * i + 1] = 0xFFFFFFFFu; continue; }
+        const double alpha = S * p + 1.0, beta = S * (1.0 - p) + 1.0;
+        const double pu = mdt_betainvcdf(alpha, beta, 0.8413447460685429);  // normcdf(1)
+        const double pl = mdt_betainvcdf(alpha, beta, 0.15865525393145705); // normcdf(-1)
+        long long l = (long long)floor(pl * (double)n), u = (long long)ceil(pu * (double)n);
+        if (l < 1) l = 1;
+        if (u > n) u = n;
+        tp[2 * i] = (unsigned int)(l - 1);
+        tp[2 * i + 1] = (unsigned int)(u - 1);
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->tpos_arr, tp, hostT.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st)); // (hostT goes out of scope)
+    // pass 2: the two order statistics, (xu - xl) / 2  (src/mcse.jl:109-117)
+    Req r2;
+    r2.mode = 5; r2.out_eb = mcse_out; r2.tpos_arr = ctx->tpos_arr;
+    return run(ctx, a, x, r2);
 }
 
 int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void* x_dcp) {

@@ -164,6 +164,18 @@ def mcse_std(x, autocov="direct", split_chains=2, maxlag=250, faithful=False):
     return out
 
 
+def mcse_quantile(x, estimator="median", prob=0.5, autocov="direct", split_chains=2, maxlag=250, faithful=False):
+    """mcse(x; kind = median) / mcse(x; kind = Fix2(quantile, prob)), src/mcse.jl:66-118"""
+    x = _as3d(x)
+    a = _args(x, estimator, autocov, split_chains, maxlag, False, prob)
+    out = np.empty(x.shape[2], x.dtype)
+    f = getattr(lib(), "mdt_oracle_mcse_quantile" + _sfx(x.dtype, faithful))
+    rc = f(ctypes.byref(a), _ptr(x), _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out
+
+
 # ---- stage functions (one parameter slice, pooled over draws and chains) ----
 def tiedrank(v):
     v = np.ascontiguousarray(np.asarray(v).ravel(order="F"))

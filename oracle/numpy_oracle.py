@@ -243,3 +243,24 @@ def mcse_std(x, s=2, maxlag=250, method="direct"):
         with np.errstate(all="ignore"):
             out[p] = np.sqrt((m4 / mv - mv) / S) / 2
     return out
+
+
+def mcse_quantile(x, estimator="median", prob=0.5, s=2, maxlag=250, method="direct"):
+    """src/mcse.jl:66-118 (scipy.special.betaincinv stands in for StatsFuns.betainvcdf)."""
+    from scipy.special import betaincinv
+    x = np.asarray(x, dtype=np.float64)
+    P = x.shape[2]
+    p = 0.5 if estimator == "median" else prob
+    S = ess_estimator(x, estimator, prob=prob, method=method, s=s, maxlag=maxlag)
+    out = np.empty(P)
+    for q in range(P):
+        if np.isnan(S[q]):
+            out[q] = np.nan
+            continue
+        v = np.sort(x[:, :, q].ravel(order="F"))
+        n = v.size
+        a, b = S[q] * p + 1, S[q] * (1 - p) + 1
+        pu, pl = betaincinv(a, b, 0.8413447460685429), betaincinv(a, b, 0.15865525393145705)
+        lo, up = max(int(np.floor(pl * n)), 1), min(int(np.ceil(pu * n)), n)
+        out[q] = (v[up - 1] - v[lo - 1]) / 2
+    return out

@@ -185,6 +185,10 @@ def estimators():
             c["mcse_std"] = co.mcse_std(x)
             if not f32:
                 agree(c["mcse_std"], no.mcse_std(x), what=name + " mcse_std")
+            for est, p in (("median", 0.5), ("quantile", 0.25), ("quantile", 0.9)):
+                c[f"mcseq|{est}|{p}"] = co.mcse_quantile(x, est, prob=p)
+                if not f32:
+                    agree(c[f"mcseq|{est}|{p}"], no.mcse_quantile(x, est, prob=p), what=name + f" mcse {est} {p}")
         np.savez_compressed(os.path.join(OUT, "est_" + name + ".npz"), **c)
         n += 1
     print("wrote", n, "estimator fixtures to", OUT)

@@ -356,6 +356,11 @@ def test_estimator_kinds(pkg, methods, name):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             assert_close(host(pkg.mcse(xd, kind=np.std)), g["mcse_std"], tol, name + " mcse_std")
+            for k, want in g.items():
+                if k.startswith("mcseq|"):  # mcse(kind = median | quantile(p)), src/mcse.jl:66-118
+                    _, est, p = k.split("|")
+                    kind = np.median if est == "median" else pkg.Quantile(float(p))
+                    assert_close(host(pkg.mcse(xd, kind=kind)), want, tol, f"{name} {k}")
 
 
 def test_mcmcchains_storage_order(pkg):
@@ -372,3 +377,16 @@ def test_mcmcchains_storage_order(pkg):
         a = pkg.ess_rhat(v)
         b = pkg.ess_rhat(dev(x))
         assert np.array_equal(host(a.ess), host(b.ess)) and np.array_equal(host(a.rhat), host(b.rhat))
+
+
+def test_fewer_draws_than_splits(pkg):
+    """draws < split_chains: niter == 0, everything is NaN (mean of nothing, src/ess_rhat.jl:391-406) -- and the
+    kernel's early exit from a parameter must not wedge the workgroup (it did once)"""
+    import torch
+    import warnings
+    x = torch.randn(3, 2, 5, dtype=torch.float64).cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = pkg.rhat(x, split_chains=4)
+        e = pkg.ess_rhat(x, split_chains=4)
+    assert np.isnan(host(r)).all() and np.isnan(host(e.ess)).all() and np.isnan(host(e.rhat)).all()

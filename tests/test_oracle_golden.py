@@ -114,4 +114,8 @@ def test_estimator_golden(name):
                 co.ess_estimator(x, est, prob=float(p), autocov=m, split_chains=int(s))
     if "mcse_std" in g:
         assert_close(co.mcse_std(x), g["mcse_std"], 1e-12, name + " mcse_std")
+    for k, want in g.items():
+        if k.startswith("mcseq|"):
+            _, est, p = k.split("|")
+            assert_close(co.mcse_quantile(x, est, prob=float(p)), want, 1e-12, f"{name} {k}")
     assert n > 0
