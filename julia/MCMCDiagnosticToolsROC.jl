@@ -142,14 +142,19 @@ end
 
 function mcse(x::AbstractArray{<:Real}; kind=Statistics.mean, autocov_method=AutocovMethod(),
               split_chains::Int=2, maxlag::Int=250)
-    kind === Statistics.mean || kind === Statistics.std ||
-        throw(ArgumentError("only kind=mean and kind=std are on the device path"))  # src/mcse.jl:45-65
+    isq = kind === Statistics.median || kind isa Base.Fix2{typeof(Statistics.quantile),<:Real}
+    kind === Statistics.mean || kind === Statistics.std || isq ||
+        throw(ArgumentError("kind must be mean, std, median or Fix2(quantile, p) on the device path"))  # src/mcse.jl:45-118
     T, x3 = _params_array(x)
     D, C, P = size(x3)
     out = Vector{T}(undef, P)
     a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL)
     GC.@preserve x3 out begin
-        if kind === Statistics.mean
+        if isq  # kind code and probability travel in the args (src/mcse.jl:66-92)
+            aq = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, kind === Statistics.median ? _EST[:median] : _EST[:quantile], 1,
+                         _code(autocov_method), split_chains, 0, 1, maxlag, kind === Statistics.median ? 0.5 : Float64(kind.x), C_NULL)
+            _check(ccall((:mdt_mcse_quantile, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), aq, x3, out))
+        elseif kind === Statistics.mean
             _check(ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
         else
             _check(ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, x3, out))
