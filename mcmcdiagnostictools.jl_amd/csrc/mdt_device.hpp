@@ -1278,6 +1278,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             if (!(iw < __builtin_inf())) iw = 0.0;
             qiw[tid] = iw;
         }
+        int wmax = 0;
         for (int c = tid; c < GRID; c += NT) {
             int h[2];
 #pragma unroll
@@ -1294,7 +1295,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 h[q] = lo;
             }
             lut[c] = (unsigned)h[0] | ((unsigned)h[1] << 16);
-            atomicMax(&ints[12], h[1] - h[0]); // widest bracket: the number of search steps every value takes
+            wmax = (h[1] - h[0]) > wmax ? (h[1] - h[0]) : wmax;
+        }
+        { // widest bracket = the number of search steps every value takes: one LDS atomic per wave
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int ov = __shfl_xor(wmax, o); wmax = ov > wmax ? ov : wmax; }
+            if (lane == 0) atomicMax(&ints[12], wmax);
         }
         if (tid == 0) { scal[21] = t0; scal[22] = top; scal[23] = ginv; }
         __syncthreads();
