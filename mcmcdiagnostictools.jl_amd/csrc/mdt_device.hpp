@@ -52,7 +52,7 @@ constexpr int BIN_OVER = NREG + 2;  // above the largest sample value
 constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless / stable sortperm)
 constexpr int NBIN = NREG + 4;
 constexpr int CH = SMALL ? (MDT_NT == 512 ? 6400 : 4096) : 13760; // elements of bin-ordered data staged in LDS per round
-constexpr int GRID = SMALL ? 1024 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
+constexpr int GRID = SMALL ? 512 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
 constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
 constexpr int TL = SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
 constexpr int MAXLAG_CAP = SMALL ? 255 : 1000;
@@ -1097,7 +1097,8 @@ constexpr int CLS_NAN = K1 + 3;
 constexpr int NBL = SMALL ? 4096 : 8192;      // local fine bins per round
 constexpr int BPT = NBL / NT;             // bins per thread in the prefix step (packed two per word)
 static_assert(BPT == 8 || BPT == 4, "prefix step: 4 or 8 bins per thread");
-constexpr int QCH = SMALL ? (MDT_NT == 512 ? 7104 : 6720) : 15104; // chunk slots of the two-level variant
+constexpr int QCH = SMALL ? (MDT_NT == 512 ? 6080 : 5440) : 15104; // chunk slots of the two-level variant
+constexpr bool USE_LBS = SMALL;           // bin id of every slot in LDS (80 KiB tables) instead of the start-bit masks
 constexpr int DENSE_ITQ = (QCH + NT - 1) / NT;
 constexpr int OFF_QT = OFF_BIG;                               // double t[K1+2]
 constexpr int OFF_QIW = OFF_QT + (K1 + 2) * 8;                // double invw[K1]
@@ -1105,9 +1106,9 @@ constexpr int OFF_QLUT = OFF_QIW + K1 * 8;                    // uint32 lut[GRID
 constexpr int OFF_QCC = OFF_QLUT + GRID * 4;                  // uint32 cc[NCLS + 4]
 constexpr int OFF_QROF = OFF_QCC + (NCLS + 4) * 4;            // uint16 rof[NCLS + 4]
 constexpr int OFF_QCUR = ((OFF_QROF + (NCLS + 4) * 2 + 3) / 4) * 4; // uint32 lcur[NBL/2 + 2] (packed u16)
-constexpr int OFF_QBST = OFF_QCUR + (NBL / 2 + 2) * 4;        // uint32 bst[QCH/32 + 2]: bin starts
-constexpr int OFF_QBRS = OFF_QBST + (QCH / 32 + 2) * 4;       // uint32 brs[QCH/32 + 2]: reserved-bin starts
-constexpr int OFF_QCHUNK = ((OFF_QBRS + (QCH / 32 + 2) * 4 + 15) / 16) * 16; // double chunk[QCH]
+constexpr int OFF_QBST = OFF_QCUR + (NBL / 2 + 2) * 4;        // uint32 bst[QCH/32 + 2]: bin starts          | uint16 lbs[QCH]: bin id
+constexpr int OFF_QBRS = OFF_QBST + (QCH / 32 + 2) * 4;       // uint32 brs[QCH/32 + 2]: reserved-bin starts |   (| 0x8000: reserved bin)
+constexpr int OFF_QCHUNK = (((USE_LBS ? OFF_QBST + QCH * 2 : OFF_QBRS + (QCH / 32 + 2) * 4) + 15) / 16) * 16; // double chunk[QCH]
 constexpr int LDS_RANKQ_END = OFF_QCHUNK + QCH * 8;
 static_assert(LDS_RANKQ_END <= LDS_BYTES, "two-level rank view exceeds the LDS carve");
 
@@ -1233,6 +1234,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     unsigned* lcur = (unsigned*)(smem + OFF_QCUR);
     unsigned* bst = (unsigned*)(smem + OFF_QBST);
     unsigned* brs = (unsigned*)(smem + OFF_QBRS);
+    unsigned short* lbs = (unsigned short*)(smem + OFF_QBST);
     double* chunk = (double*)(smem + OFF_QCHUNK);
     unsigned* cc2 = (unsigned*)(smem + OFF_CC2);
     unsigned* segcur = (unsigned*)(smem + OFF_TSEG);
@@ -1528,7 +1530,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         F2 = F2 > 4096 ? 4096 : F2;
         const double f2m1 = (double)(F2 - 1);
         for (int i = tid; i < NBL / 2 + 2; i += NT) lcur[i] = 0u;
-        for (int i = tid; i < QCH / 32 + 2; i += NT) { bst[i] = 0u; brs[i] = 0u; }
+        if (!USE_LBS) { for (int i = tid; i < QCH / 32 + 2; i += NT) { bst[i] = 0u; brs[i] = 0u; } }
         if (segout && tid < NJe) {
             const unsigned st = segsave[r * NJe + tid], c = segsave[r * NJe + tid + 1] - st, done = cumj[tid];
             adj2[tid] = (int)((unsigned)tid * uniter + done) - (int)(st - base);
@@ -1537,6 +1539,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         __syncthreads();
         unsigned pv[DENSE_ITQ];
         unsigned fmask = 0u; // slots of this thread that hold the first draw of a split chain
+        unsigned rmask = 0u; // ... that fall into a reserved bin (value == splitter)
         unsigned jpk[(DENSE_ITQ + 3) / 4]; // split-chain slot of every member, 8 bits each
 #pragma unroll
         for (int k = 0; k < (DENSE_ITQ + 3) / 4; ++k) jpk[k] = 0u;
@@ -1585,6 +1588,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                         const int subr = (v == tk2[kk]) ? 0 : 1 + (int)f;        // inside a regular bucket
                         const int sub = (cls >= 1 && cls <= K1) ? subr : ((cls == K1 + 1) ? 0 : 1);
                         lb[k] = (cls - clo) * F2 + sub;
+                        rmask |= (sub == 0 ? 1u : 0u) << k;
                     }
                 }
             }
@@ -1610,7 +1614,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 for (int q = 0; q < BPT / 2; ++q) lcur[(BPT / 2) * tid + q] = (b0 + s8[2 * q]) | ((b0 + s8[2 * q + 1]) << 16);
 #pragma unroll
                 for (int q = 0; q < BPT; ++q) {
-                    if (c8[q]) {
+                    if (!USE_LBS && c8[q]) {
                         const unsigned st = b0 + s8[q];
                         atomicOr(&bst[st >> 5], 1u << (st & 31));
                         if (((BPT * tid + q) % F2) == 0) atomicOr(&brs[st >> 5], 1u << (st & 31));
@@ -1628,7 +1632,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 }
             }
 #pragma unroll
-            for (int k = 0; k < DENSE_ITQ; ++k) { if ((unsigned)(k * NT + tid) < cnt) chunk[pv[k]] = xv[k]; }
+            for (int k = 0; k < DENSE_ITQ; ++k) {
+                if ((unsigned)(k * NT + tid) < cnt) {
+                    chunk[pv[k]] = xv[k];
+                    if (USE_LBS) lbs[pv[k]] = (unsigned short)((unsigned)lb[k] | ((rmask >> k & 1u) << 15));
+                }
+            }
         }
         __syncthreads();
         MDT_PROF_MARK(PH_R_PLACE);
@@ -1643,18 +1652,30 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             res[k] = 2u;
             if (i < cnt) {
                 const double v = chunk[i];
-                // bin bounds from the start-bit mask: last start <= i, next start > i
-                int wi = (int)(i >> 5);
-                unsigned mk = bst[wi] & (0xFFFFFFFFu >> (31 - (i & 31)));
-                while (mk == 0u) mk = bst[--wi];
-                const unsigned st = ((unsigned)wi << 5) + 31u - (unsigned)__clz((int)mk);
-                int wj = (int)(i >> 5);
-                unsigned mn = ((i & 31) == 31) ? 0u : (bst[wj] & (0xFFFFFFFEu << (i & 31)));
-                while (mn == 0u && ++wj < nwm) mn = bst[wj];
-                unsigned en = mn ? ((unsigned)wj << 5) + (unsigned)(__ffs((int)mn) - 1) : cnt;
-                en = en < cnt ? en : cnt;
+                unsigned st, en;
+                bool rsv;
+                if (USE_LBS) {
+                    // bin id of the slot -> bounds from the packed ends (the end of bin b-1 is the start of bin b)
+                    const unsigned tg = lbs[i], b = tg & 0x7FFFu, bm = b > 0u ? b - 1u : 0u;
+                    const unsigned wa = lcur[b >> 1], wb = lcur[bm >> 1];
+                    en = (b & 1u) ? wa >> 16 : wa & 0xFFFFu;
+                    st = (b == 0u) ? 0u : ((bm & 1u) ? wb >> 16 : wb & 0xFFFFu);
+                    rsv = (tg >> 15) != 0u;
+                } else {
+                    // bin bounds from the start-bit mask: last start <= i, next start > i
+                    int wi = (int)(i >> 5);
+                    unsigned mk = bst[wi] & (0xFFFFFFFFu >> (31 - (i & 31)));
+                    while (mk == 0u) mk = bst[--wi];
+                    st = ((unsigned)wi << 5) + 31u - (unsigned)__clz((int)mk);
+                    int wj = (int)(i >> 5);
+                    unsigned mn = ((i & 31) == 31) ? 0u : (bst[wj] & (0xFFFFFFFEu << (i & 31)));
+                    while (mn == 0u && ++wj < nwm) mn = bst[wj];
+                    en = mn ? ((unsigned)wj << 5) + (unsigned)(__ffs((int)mn) - 1) : cnt;
+                    en = en < cnt ? en : cnt;
+                    rsv = ((brs[st >> 5] >> (st & 31)) & 1u) != 0u;
+                }
                 unsigned less = base + st, eq;
-                if ((brs[st >> 5] >> (st & 31)) & 1u) {
+                if (rsv) {
                     eq = en - st;
                 } else {
                     eq = 0;
