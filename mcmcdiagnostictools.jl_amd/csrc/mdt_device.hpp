@@ -1506,6 +1506,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     }
     __syncthreads(); // the segments are complete in global memory
     MDT_PROF_MARK(MDT_PROF_QSEL(PH_R_PLACE, 13));
+    const unsigned zdense = (unsigned)(2 * n + 1); // start of the dense whole-rank copy in ztab (3n + 2 entries < 2^32)
     const Fx fx = Fx::make(kp.niter);
     if (momout) { // (the bytes held the partition's tables until here)
         if (tid < 65) { mS1[tid] = 0; mS2[tid] = 0; mOr[tid] = 0ull; mAnd[tid] = ~0ull; }
@@ -1704,7 +1705,10 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         if (!noout) {
             double zz[DENSE_ITQ];
 #pragma unroll
-            for (int k = 0; k < DENSE_ITQ; ++k) zz[k] = store_r2 ? (double)res[k] : ((res[k] & 1u) ? ztab[res[k]] : ztab[2 * n + 1 + (res[k] >> 1)]);
+            for (int k = 0; k < DENSE_ITQ; ++k) { // whole ranks read the dense copy behind the doubled-rank table (32-bit index math)
+                const unsigned zi = (res[k] & 1u) ? res[k] : zdense + (res[k] >> 1);
+                zz[k] = store_r2 ? (double)res[k] : ztab[zi];
+            }
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < DENSE_ITQ; ++k) {
