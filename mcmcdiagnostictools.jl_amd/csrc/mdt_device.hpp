@@ -1258,12 +1258,12 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
 
     // ---- sample -> sorted positions -> coarse splitters -> grid LUT
     {
-        const long long items = (n + NT - 1) / NT;
-        long long js = tid % items;
-        if (js * NT + tid >= n && js > 0) --js;
-        long long es = js * NT + tid;
-        if (es >= n) es = (long long)(tid % n);
-        double v = vg(es);
+        const unsigned un = (unsigned)n, items = (un + NT - 1u) / NT; // (n < 2^31: 32-bit index math)
+        unsigned js = (unsigned)tid % items;
+        if (js * NT + (unsigned)tid >= un && js > 0u) --js;
+        unsigned es = js * NT + (unsigned)tid;
+        if (es >= un) es = (unsigned)tid % un;
+        double v = vg.at(0, es);
         if (v != v) v = __builtin_inf();
         const int spos = wg_sample_rank(v, tx);
         if ((spos & 3) == 0) qt[spos >> 2] = v;
