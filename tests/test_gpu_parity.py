@@ -390,3 +390,58 @@ def test_fewer_draws_than_splits(pkg):
         r = pkg.rhat(x, split_chains=4)
         e = pkg.ess_rhat(x, split_chains=4)
     assert np.isnan(host(r)).all() and np.isnan(host(e.ess)).all() and np.isnan(host(e.rhat)).all()
+
+
+def test_fuzz_shapes_and_kinds(pkg, methods):
+    """seeded random shapes / splits / data flavours through every kind, against the oracle"""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(20261003)
+    flavours = ("normal", "ar", "ties", "skew", "offset")
+    for it in range(36):
+        D = int(rng.integers(6, 2500))
+        C = int(rng.integers(1, 7))
+        P = int(rng.integers(1, 5))
+        s = int(rng.integers(1, 4))
+        fl = flavours[it % len(flavours)]
+        if fl == "normal":
+            x = rng.standard_normal((D, C, P))
+        elif fl == "ar":
+            x = ar1(float(rng.uniform(-0.9, 0.95)), D, C, P, rng)
+        elif fl == "ties":
+            x = rng.integers(0, int(rng.integers(2, 40)), size=(D, C, P)).astype(np.float64)
+        elif fl == "skew":
+            x = np.exp(3.0 * rng.standard_normal((D, C, P)))
+        else:
+            x = rng.standard_normal((D, C, P)) + 3.0 * rng.standard_normal((1, C, 1)) + 1e6
+        ml = int(rng.choice([1, 3, 50, 250]))
+        m = ("direct", "fft", "bda")[it % 3]
+        xd = dev(x)
+        what = f"it={it} {fl} D={D} C={C} P={P} s={s} ml={ml} {m}"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for kind in KINDS:
+                S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
+                We, Wr = co.ess_rhat(x, kind=kind, autocov=m, split_chains=s, maxlag=ml)
+                assert_close(host(S), We, 1e-8, what + f" ess {kind}")
+                assert_close(host(R), Wr, 1e-8, what + f" rhat {kind}")
+            for est, kind in (("median", np.median), ("mad", "mad"), ("std", np.std)):
+                got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
+                assert_close(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), 1e-8, what + " " + est)
+
+
+def test_long_heavy_tailed_slices(pkg):
+    """n = 240_000 per parameter, log-normal with sigma 4 (the sample quantiles crowd into a few grid cells: the
+    class search takes its maximum number of steps) and a Cauchy column; both workgroup geometries rank it alike"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(424242)
+    D, C = 40_000, 6
+    x = np.stack([np.exp(4.0 * rng.standard_normal((D, C))), rng.standard_cauchy((D, C)), ar1(0.5, D, C, 1, rng)[:, :, 0]], axis=2)
+    xd = dev(x)
+    r, _ = pkg.rank_normalize(xd)
+    for p in range(3):
+        assert np.array_equal(host(r)[:, :, p], co.tiedrank(x[:, :, p].ravel(order="F")).reshape(D, C, order="F")), p
+    got = [host(o) for o in pkg.bulk_tail(xd)]
+    want = co.bulk_tail(x)
+    for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+        assert_close(a, b, RTOL64, nm)
