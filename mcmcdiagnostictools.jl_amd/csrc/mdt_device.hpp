@@ -1,28 +1,28 @@
 // mdt_device.hpp -- device code of the MI355X (gfx950) ESS / R-hat engine.
 //
-// One 1024-thread workgroup (16 wave64) owns one parameter at a time and walks the params axis
-// persistently (grid = #CUs; the 150 KB LDS working set allows one workgroup per CU).  For a
-// parameter slice x[0..n), n = draws*chains (column-major, draws fastest) it runs, all on chip:
+// One persistent launch; a workgroup owns one parameter at a time (parameters are handed out by an atomic
+// ticket).  For a parameter slice x[0..n), n = draws*chains (column-major, draws fastest) it runs, on chip:
 //
-//   rank phase    pooled tied ranks of x (or of |x - median|) WITHOUT a sort: a 1024-element
-//                 sample is bitonic-sorted, 256 sample quantiles become coarse splitters, each
-//                 coarse bucket is cut linearly into 31 fine bins (+1 bin reserved for values
-//                 equal to the splitter), an LDS histogram + prefix gives every bin its rank
-//                 base, and the rank inside a bin (~5 elements) is an all-pairs count against
-//                 the bin's members staged in LDS, ~14K elements per round.  Exact for any
-//                 input: binning only has to be monotone, ties/NaN/Inf/-0.0 follow
-//                 StatsBase.tiedrank + isless (src/utils.jl:180).  Order statistics (median,
-//                 type-7 quantile neighbours) drop out of the same counting step.
-//   series phase  split-chain means, variances, lagged products (src/ess_rhat.jl:526-551,
-//                 161-179) from an LDS-staged, centred tile of the series; lags are computed
-//                 lazily in blocks and Geyer's initial monotone sequence (:555-594) runs on one
-//                 lane between blocks, so well-mixed chains stop after 16 lags.
-//   indicator     tail-ESS (src/ess_rhat.jl:301-311, 647-659): the quantile indicators are
-//                 bit-vectors, their autocovariance is popcount(bits & bits>>k), exact integers.
+//   rank phase    pooled tied ranks of x (or of |x - median|) WITHOUT a sort.  Default (rank_phase_q, two
+//                 levels): NT sample values are sorted, every 4th becomes a coarse splitter; a histogram pass
+//                 counts the coarse classes, maximal runs of classes that fit the LDS chunk become rounds, a
+//                 partition pass groups the slice by round (and split chain); every round re-cuts ITS value
+//                 range into up to 4096 local fine bins (one per bucket reserved for values equal to the
+//                 splitter), an LDS histogram + prefix gives every bin its rank base, and the rank inside a bin
+//                 (~1.5 members) is an all-pairs count against the bin's members in LDS.  Exact for any input:
+//                 binning only has to be monotone, ties/NaN/Inf/-0.0 follow StatsBase.tiedrank + isless
+//                 (src/utils.jl:180).  Order statistics (median, type-7 quantile neighbours) drop out of the
+//                 same counting step.  rank_phase_b / rank_phase_p are the single-level formulations (the
+//                 fallback for a point mass larger than the chunk; bit-identical ranks).
+//   series phase  split-chain means, variances, lagged products (src/ess_rhat.jl:526-551, 161-179) from an
+//                 LDS-resident chain; lags are computed lazily in blocks and Geyer's initial monotone sequence
+//                 (:555-594) runs on one lane between blocks, so well-mixed chains stop after 32 lags.  The
+//                 moments of a rank-normalised series are exact fixed-point sums (order independent).
+//   indicator     tail-ESS (src/ess_rhat.jl:301-311, 647-659): the quantile indicators are bit-vectors, their
+//                 autocovariance is popcount(bits & bits>>k), exact integers.
 //
-// Everything is deterministic (no floating-point atomics; fixed reduction trees), which the
-// reference's tests demand (test/ess_rhat.jl:167-204: results identical wherever a parameter
-// sits in the batch).
+// Everything is deterministic (no floating-point atomics), which the reference's tests demand
+// (test/ess_rhat.jl:167-204: results identical wherever a parameter sits in the batch).
 //
 // The file is included several times by mdt_hip.hip, into one namespace per workgroup geometry:
 //   MDT_NT 1024, MDT_LDS_LIMIT 160 KiB, 4 waves/SIMD  one workgroup per CU: long chains, big FFTs, maxlag <= 1000
