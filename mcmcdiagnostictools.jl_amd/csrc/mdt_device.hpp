@@ -2719,7 +2719,9 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
 
     long long k0 = 0;
     while (true) {
-        long long kend = k0 + 64;
+        // 16 lags per block: a wave covers one unit as 16 lags x 4 word-segments, so that a well-mixed chain (Geyer
+        // stops after a few lags) costs a quarter of a 64-lag block
+        long long kend = k0 + 16;
         if (kend > maxlag + 1) kend = maxlag + 1;
         // units (chain, indicator) are stored with a stride of nwU words: nwS words of bits (tail masked) and
         // zero words behind them, so that a shifted read never needs a bounds check
@@ -2742,23 +2744,31 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
             __syncthreads();
             for (int u = w; u < 2 * nb; u += NWAVE) {
                 const unsigned long long* sb = sb2 + u * nwU;
-                const long long k = k0 + lane;
-                long long Sx = 0, Ak = 0, Hk = 0, Tk = 0;
-                double ck = 0.0, dk = 0.0;
+                const int kl = lane & 15, seg = lane >> 4;
+                const long long k = k0 + kl;
+                const int wq = (nwS + 3) >> 2, i0 = seg * wq, i1 = (i0 + wq < nwS) ? i0 + wq : nwS;
+                int sxp = 0, akp = 0; // this lane's word segment
                 if (k < kend) {
                     // A_k = sum_t I_t I_{t+k}: the only sum that needs the whole chain per lag.  S is the same
                     // for every lag; T_k = ones in [k, n) = S - ones in [0, k); H_k = ones in [0, n-k) =
                     // S - ones in [n-k, n): a few words each.
                     const int q = (int)(k >> 6), r = (int)(k & 63);
-                    unsigned long long lo = sb[q];
-                    for (int i = 0; i < nwS; ++i) {
+                    unsigned long long lo = sb[i0 + q];
+                    for (int i = i0; i < i1; ++i) {
                         const unsigned long long v = sb[i];
                         const unsigned long long hi = sb[i + q + 1];
                         const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
-                        Sx += __popcll(v);
-                        Ak += __popcll(v & vs);
+                        sxp += __popcll(v);
+                        akp += __popcll(v & vs);
                         lo = hi;
                     }
+                }
+                sxp += __shfl_xor(sxp, 16); sxp += __shfl_xor(sxp, 32); // the 4 segments of a lag (exact integers)
+                akp += __shfl_xor(akp, 16); akp += __shfl_xor(akp, 32);
+                long long Sx = sxp, Ak = akp, Hk = 0, Tk = 0;
+                double ck = 0.0, dk = 0.0;
+                if (k < kend && seg == 0) {
+                    const int q = (int)(k >> 6);
                     long long head = 0, tail = 0; // ones among the first k / the last k positions
                     for (int i = 0; i <= q; ++i) {
                         const long long nb2 = k - ((long long)i << 6); // bits of word i that belong to [0, k)
@@ -2784,8 +2794,10 @@ MDT_PHASE double indicator_phase_pooled(const KP& kp_, const T* xp_, T qlo_, T q
                     dk = (double)(Hk + Tk - 2 * Ak);
                     if (k == 0) imean[(u & 1) * MAXM + jb + (u >> 1)] = (double)Sx / dn;
                 }
-                itab[u * 64 + lane] = ck;
-                itab[(2 * IND_CB + u) * 64 + lane] = dk;
+                if (seg == 0) {
+                    itab[u * 64 + kl] = ck;
+                    itab[(2 * IND_CB + u) * 64 + kl] = dk;
+                }
             }
             __syncthreads();
             // fixed-order sum over the chains of this batch
