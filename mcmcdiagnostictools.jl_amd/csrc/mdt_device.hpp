@@ -1532,7 +1532,6 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
         const double f2m1 = (double)(F2 - 1);
         for (int i = tid; i < NBL / 2 + 2; i += NT) lcur[i] = 0u;
         if (!USE_LBS) { for (int i = tid; i < QCH / 32 + 2; i += NT) { bst[i] = 0u; brs[i] = 0u; } }
-        if (USE_LBS && tid == 0) { ints[17] = 0; ints[18] = 0; ints[19] = 0; } // crowded bins / their members / list fill
         if (segout && tid < NJe) {
             const unsigned st = segsave[r * NJe + tid], c = segsave[r * NJe + tid + 1] - st, done = cumj[tid];
             adj2[tid] = (int)((unsigned)tid * uniter + done) - (int)(st - base);
@@ -1614,14 +1613,6 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 const unsigned b0 = woff + incl - tot;
 #pragma unroll
                 for (int q = 0; q < BPT / 2; ++q) lcur[(BPT / 2) * tid + q] = (b0 + s8[2 * q]) | ((b0 + s8[2 * q + 1]) << 16);
-                if (USE_LBS) { // crowded bins (more than 4 members, not reserved) are ranked by a compacted pass below
-                    unsigned ob = 0u, om = 0u;
-#pragma unroll
-                    for (int q = 0; q < BPT; ++q) {
-                        if (c8[q] > 4u && ((BPT * tid + q) % F2) != 0) { ++ob; om += c8[q]; }
-                    }
-                    if (ob) { atomicAdd(&ints[17], (int)ob); atomicAdd(&ints[18], (int)om); }
-                }
 #pragma unroll
                 for (int q = 0; q < BPT; ++q) {
                     if (!USE_LBS && c8[q]) {
@@ -1656,131 +1647,6 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
             if (tpos[t] - base < cnt) { tg0 = t < tg0 ? t : tg0; tg1 = t + 1; }
         unsigned res[DENSE_ITQ];
         const int nwm = (int)((cnt + 31) >> 5);
-        // Ranking inside the bins, 80 KiB geometry.  (A) one lane per BIN: bins of up to 4 members -- 9 members in 10 --
-        // are ranked from registers, straight-line (6 pairs); the doubled rank replaces the value in LDS, tagged by
-        // an all-ones high word (no value of a round is a NaN).  (B) the members of the crowded bins, compacted, one
-        // lane per member.  (C) one lane per SLOT: pick the rank up (reserved bins: all tied, from the bin bounds).
-        constexpr int OV_CAP = 384;
-        const bool binpass = USE_LBS && ints[17] <= OV_CAP && ints[18] <= 2 * NT;
-        if (binpass) {
-            unsigned short* ovl = (unsigned short*)(smem + OFF_QLUT);        // crowded bins (the LUT is idle in the rounds)
-            unsigned short* ovp = ovl + OV_CAP;                              // inclusive prefix of their sizes
-            unsigned long long* chunk64 = (unsigned long long*)chunk;
-            constexpr unsigned long long RTAG = 0xFFFFFFFF00000000ull;
-            // ---- (A)
-#pragma unroll
-            for (int k = 0; k < NBL / NT; ++k) {
-                const unsigned b = (unsigned)(k * NT + tid), bm = b > 0u ? b - 1u : 0u;
-                const unsigned wa = lcur[b >> 1], wb = lcur[bm >> 1];
-                const unsigned en = (b & 1u) ? wa >> 16 : wa & 0xFFFFu;
-                const unsigned st = (b == 0u) ? 0u : ((bm & 1u) ? wb >> 16 : wb & 0xFFFFu);
-                const unsigned len = en - st;
-                const unsigned stc = st < cnt ? st : cnt - 1u;
-                const unsigned rsv = (unsigned)lbs[stc] >> 15; // (meaningful when len > 0)
-                const unsigned last = en - 1u;
-                double y[4];
-#pragma unroll
-                for (int m2 = 0; m2 < 4; ++m2) { const unsigned sl = st + (unsigned)m2; y[m2] = chunk[len ? (sl <= last ? sl : last) : stc]; }
-                if (len > 4u && !rsv) {
-                    const int idx = atomicAdd(&ints[19], 1);
-                    if (idx < OV_CAP) ovl[idx] = (unsigned short)b;
-                }
-                const bool small = len >= 1u && len <= 4u && !rsv;
-                unsigned lt[4] = {0u, 0u, 0u, 0u}, eq[4] = {1u, 1u, 1u, 1u};
-#pragma unroll
-                for (int p1 = 0; p1 < 4; ++p1) {
-#pragma unroll
-                    for (int p2 = p1 + 1; p2 < 4; ++p2) {
-                        const bool in = (unsigned)p2 < len;
-                        const bool l12 = y[p1] < y[p2], e12 = y[p1] == y[p2];
-                        lt[p2] += (in && l12) ? 1u : 0u;         // p1 precedes p2
-                        lt[p1] += (in && !l12 && !e12) ? 1u : 0u; // p2 precedes p1
-                        eq[p1] += (in && e12) ? 1u : 0u;
-                        eq[p2] += (in && e12) ? 1u : 0u;
-                    }
-                }
-#pragma unroll
-                for (int m2 = 0; m2 < 4; ++m2) {
-                    if (small && (unsigned)m2 < len) {
-                        const unsigned less = base + st + lt[m2];
-                        for (int t = tg0; t < tg1; ++t)
-                            if (tpos[t] - less < eq[m2]) ostat[t] = y[m2];
-                        chunk64[st + (unsigned)m2] = RTAG | (unsigned long long)(2u * less + eq[m2] + 1u);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- (B)
-            const int nov = ints[19] < OV_CAP ? ints[19] : OV_CAP;
-            {
-                unsigned ln = 0u;
-                if (tid < nov) {
-                    const unsigned b = ovl[tid], bm = b - 1u; // (a crowded bin is never bin 0 of a round: that one is reserved or "under")
-                    const unsigned wa = lcur[b >> 1], wb = lcur[bm >> 1];
-                    const unsigned en = (b & 1u) ? wa >> 16 : wa & 0xFFFFu;
-                    const unsigned st = (b == 0u) ? 0u : ((bm & 1u) ? wb >> 16 : wb & 0xFFFFu);
-                    ln = en - st;
-                }
-                const unsigned incl = wave_incl_scan_u32(ln);
-                if (lane == 63) wtot[w] = incl;
-                __syncthreads();
-                unsigned woff = 0;
-                for (int q2 = 0; q2 < w; ++q2) woff += wtot[q2];
-                if (tid < nov) ovp[tid] = (unsigned short)(woff + incl);
-            }
-            __syncthreads();
-            const unsigned novm = nov ? (unsigned)ovp[nov - 1] : 0u;
-            unsigned orr[2] = {0u, 0u}, osl[2] = {0u, 0u};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const unsigned g = (unsigned)(h * NT + tid);
-                if (g < novm) {
-                    int lo2 = 0, hi2 = nov - 1; // first entry whose inclusive prefix exceeds g
-                    while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if ((unsigned)ovp[mid] > g) hi2 = mid; else lo2 = mid + 1; }
-                    const unsigned b = ovl[lo2], bm = b - 1u;
-                    const unsigned wa = lcur[b >> 1], wb = lcur[bm >> 1];
-                    const unsigned en = (b & 1u) ? wa >> 16 : wa & 0xFFFFu;
-                    const unsigned st = (b == 0u) ? 0u : ((bm & 1u) ? wb >> 16 : wb & 0xFFFFu);
-                    const unsigned mme = g - ((unsigned)ovp[lo2] - (en - st));
-                    const double v = chunk[st + mme];
-                    unsigned lt2 = 0u, eq2 = 0u;
-                    for (unsigned sl = st; sl < en; ++sl) {
-                        const double yy = chunk[sl];
-                        lt2 += (yy < v) ? 1u : 0u;
-                        eq2 += (yy == v) ? 1u : 0u;
-                    }
-                    const unsigned less = base + st + lt2;
-                    for (int t = tg0; t < tg1; ++t)
-                        if (tpos[t] - less < eq2) ostat[t] = v;
-                    orr[h] = 2u * less + eq2 + 1u;
-                    osl[h] = st + mme + 1u;
-                }
-            }
-            __syncthreads(); // every member of a crowded bin was read: now the ranks may replace the values
-#pragma unroll
-            for (int h = 0; h < 2; ++h) { if (osl[h]) chunk64[osl[h] - 1u] = RTAG | (unsigned long long)orr[h]; }
-            __syncthreads();
-            // ---- (C)
-#pragma unroll
-            for (int k = 0; k < DENSE_ITQ; ++k) {
-                const unsigned i0 = (unsigned)(k * NT + tid);
-                const unsigned i = i0 < cnt ? i0 : cnt - 1u;
-                const unsigned long long w64 = chunk64[i];
-                unsigned r2 = (unsigned)w64;
-                if ((unsigned)(w64 >> 32) != 0xFFFFFFFFu) { // a reserved bin: one value only, all tied
-                    const unsigned tg = lbs[i], b = tg & 0x7FFFu, bm = b > 0u ? b - 1u : 0u;
-                    const unsigned wa = lcur[b >> 1], wb = lcur[bm >> 1];
-                    const unsigned en = (b & 1u) ? wa >> 16 : wa & 0xFFFFu;
-                    const unsigned st = (b == 0u) ? 0u : ((bm & 1u) ? wb >> 16 : wb & 0xFFFFu);
-                    const unsigned less = base + st, eq2 = en - st;
-                    if (i0 < cnt)
-                        for (int t = tg0; t < tg1; ++t)
-                            if (tpos[t] - less < eq2) ostat[t] = __longlong_as_double((long long)w64);
-                    r2 = 2u * less + eq2 + 1u;
-                }
-                res[k] = (i0 < cnt) ? r2 : 2u;
-            }
-        } else {
 #pragma unroll
         for (int k = 0; k < DENSE_ITQ; ++k) {
             const unsigned i = (unsigned)(k * NT + tid);
@@ -1835,7 +1701,6 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                 for (int t = tg0; t < tg1; ++t)
                     if (tpos[t] - less < eq) ostat[t] = v;
             }
-        }
         }
         if (!noout) {
             double zz[DENSE_ITQ];
