@@ -363,6 +363,20 @@ def test_estimator_kinds(pkg, methods, name):
                     assert_close(host(pkg.mcse(xd, kind=kind)), want, tol, f"{name} {k}")
 
 
+def test_estimators_from_host_memory(pkg):
+    """numpy input (MDT_HOST staging) through the estimator entry points, incl. the two-pass mdt_mcse_quantile"""
+    import warnings
+    g = load_golden("est_ar1_500x4x10")
+    x = load_golden("ar1_500x4x10")["x"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert_close(pkg.ess(x, kind=np.median), g["est|median|0.5|direct|2"], RTOL64, "median host")
+        assert_close(pkg.ess(x, kind=pkg.Quantile(0.9)), g["est|quantile|0.9|direct|2"], RTOL64, "q host")
+        assert_close(pkg.mcse(x, kind=np.std), g["mcse_std"], RTOL64, "mcse std host")
+        assert_close(pkg.mcse(x, kind=np.median), g["mcseq|median|0.5"], RTOL64, "mcse median host")
+        assert_close(pkg.mcse(x, kind=pkg.Quantile(0.25)), g["mcseq|quantile|0.25"], RTOL64, "mcse q host")
+
+
 def test_mcmcchains_storage_order(pkg):
     """(iterations, parameters, chains) input -- MCMCChains storage -- through the device-side permutation"""
     import torch
