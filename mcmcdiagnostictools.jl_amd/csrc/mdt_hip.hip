@@ -36,7 +36,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
+#include <vector>
 
 using mdtc::KP;
 
@@ -109,7 +112,7 @@ static double mdt_betacf(double a, double b, double x) {
         d = 1.0 / d;
         const double de = d * c;
         h *= de;
-        if (fabs(de - 1.0) < 1e-16) break;
+        if (fabs(de - 1.0) < 3e-16) break;
     }
     return h;
 }
@@ -123,6 +126,12 @@ static double mdt_ibeta(double a, double b, double x) {
 }
 static double mdt_betainvcdf(double a, double b, double p) {
     double lo = 0.0, hi = 1.0, x = a / (a + b);
+    { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
+        const double sd = sqrt(a * b / ((a + b) * (a + b) * (a + b + 1.0)));
+        const double z = (p > 0.0 && p < 1.0) ? 0.5513288954217921 * log(p / (1.0 - p)) * 1.0 : 0.0; /* sqrt(3)/pi * logit */
+        const double x0 = x + z * sd;
+        if (x0 > 0.0 && x0 < 1.0) x = x0;
+    }
     const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
     for (int it = 0; it < 200; ++it) {
         const double f = mdt_ibeta(a, b, x) - p;
@@ -130,7 +139,7 @@ static double mdt_betainvcdf(double a, double b, double p) {
         const double pdf = (x > 0.0 && x < 1.0) ? exp((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lb) : 0.0;
         double xn = (pdf > 0.0) ? x - f / pdf : 0.5 * (lo + hi);
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (fabs(xn - x) <= 1e-16 * x) { x = xn; break; }
+        if (fabs(xn - x) <= 4e-16 * x) { x = xn; break; } /* (two neighbouring doubles would otherwise alternate until the cap) */
         x = xn;
     }
     return x;
@@ -589,17 +598,32 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
     // positions of the two quadrature points of the Beta error distribution (src/mcse.jl:93-108)
     std::string hostT((size_t)P * 2 * sizeof(unsigned int), '\0');
     unsigned int* tp = (unsigned int*)&hostT[0];
-    for (long long i = 0; i < P; ++i) {
-        const double S = (a->dtype == MDT_F32) ? (double)((const float*)&hostS[0])[i] : ((const double*)&hostS[0])[i];
-        if (S != S) { tp[2 * i] = 0xFFFFFFFFu; tp[2 * i + 1] = 0xFFFFFFFFu; continue; }
-        const double alpha = S * p + 1.0, beta = S * (1.0 - p) + 1.0;
-        const double pu = mdt_betainvcdf(alpha, beta, 0.8413447460685429);  // normcdf(1)
-        const double pl = mdt_betainvcdf(alpha, beta, 0.15865525393145705); // normcdf(-1)
-        long long l = (long long)floor(pl * (double)n), u = (long long)ceil(pu * (double)n);
-        if (l < 1) l = 1;
-        if (u > n) u = n;
-        tp[2 * i] = (unsigned int)(l - 1);
-        tp[2 * i + 1] = (unsigned int)(u - 1);
+    {
+        const char* hs = &hostS[0];
+        const int f32 = a->dtype == MDT_F32;
+        auto work = [=](long long i0, long long i1) {
+            for (long long i = i0; i < i1; ++i) {
+                const double S = f32 ? (double)((const float*)hs)[i] : ((const double*)hs)[i];
+                if (S != S) { tp[2 * i] = 0xFFFFFFFFu; tp[2 * i + 1] = 0xFFFFFFFFu; continue; }
+                const double alpha = S * p + 1.0, beta = S * (1.0 - p) + 1.0;
+                const double pu = mdt_betainvcdf(alpha, beta, 0.8413447460685429);  // normcdf(1)
+                const double pl = mdt_betainvcdf(alpha, beta, 0.15865525393145705); // normcdf(-1)
+                long long l = (long long)floor(pl * (double)n), u = (long long)ceil(pu * (double)n);
+                if (l < 1) l = 1;
+                if (u > n) u = n;
+                tp[2 * i] = (unsigned int)(l - 1);
+                tp[2 * i + 1] = (unsigned int)(u - 1);
+            }
+        };
+        // independent per parameter: a few host threads for big batches (~30 us of scalar math each)
+        unsigned nth = std::thread::hardware_concurrency();
+        nth = nth > 16 ? 16 : (nth < 1 ? 1 : nth);
+        if (P < 512) nth = 1;
+        std::vector<std::thread> th;
+        const long long per = (P + nth - 1) / nth;
+        for (unsigned t = 1; t < nth; ++t) th.emplace_back(work, (long long)t * per, std::min(P, (long long)(t + 1) * per));
+        work(0, std::min(P, per));
+        for (auto& t : th) t.join();
     }
     HIP_TRY(hipMemcpyAsync(ctx->tpos_arr, tp, hostT.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st)); // (hostT goes out of scope)

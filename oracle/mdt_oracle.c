@@ -119,7 +119,7 @@ static double mdto_betacf(double a, double b, double x) {
         d = 1.0 / d;
         const double de = d * c;
         h *= de;
-        if (fabs(de - 1.0) < 1e-16) break;
+        if (fabs(de - 1.0) < 3e-16) break;
     }
     return h;
 }
@@ -133,6 +133,12 @@ static double mdto_ibeta(double a, double b, double x) {
 }
 static double mdto_betainvcdf(double a, double b, double p) {
     double lo = 0.0, hi = 1.0, x = a / (a + b);
+    { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
+        const double sd = sqrt(a * b / ((a + b) * (a + b) * (a + b + 1.0)));
+        const double z = (p > 0.0 && p < 1.0) ? 0.5513288954217921 * log(p / (1.0 - p)) * 1.0 : 0.0; /* sqrt(3)/pi * logit */
+        const double x0 = x + z * sd;
+        if (x0 > 0.0 && x0 < 1.0) x = x0;
+    }
     const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
     for (int it = 0; it < 200; ++it) {
         const double f = mdto_ibeta(a, b, x) - p;
@@ -140,7 +146,7 @@ static double mdto_betainvcdf(double a, double b, double p) {
         const double pdf = (x > 0.0 && x < 1.0) ? exp((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lb) : 0.0;
         double xn = (pdf > 0.0) ? x - f / pdf : 0.5 * (lo + hi);
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (fabs(xn - x) <= 1e-16 * x) { x = xn; break; }
+        if (fabs(xn - x) <= 4e-16 * x) { x = xn; break; } /* (two neighbouring doubles would otherwise alternate until the cap) */
         x = xn;
     }
     return x;
