@@ -117,6 +117,7 @@ struct KP {
     int relative;
     int fold;                   // rank_normalize stage: rank |x - median| instead of x
     const unsigned int* tpos_arr; // mode 5: [P][2] zero-based sorted positions (l-1, u-1) per parameter; 0xFFFFFFFF: NaN
+    int fft_lds;                // FFTAutocovMethod: 1 = run the in-LDS transform when it fits (MDT_FFT_LDS=1), 0 = lagged products
     int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
@@ -2962,11 +2963,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             continue;
         }
 
-        // FFTAutocovMethod: the in-LDS transform when the padded chain fits; longer chains get the same linear
-        // autocorrelation from lagged products (zero padding makes the transform's result exactly those sums:
-        // ac_k / ac_0 * var_j * (niter-1)/niter == sum_t c_t c_{t+k} / niter), plus the one place where the
-        // formulas differ: a constant split chain is 0/0 = NaN in the reference (src/ess_rhat.jl:192).
-        const bool fft_lds = kp.method == 1 && kp.niter + kp.maxlag + 1 <= FFT_MAXN;
+        // FFTAutocovMethod: by default the same linear autocorrelation from lagged products (zero padding makes the
+        // transform's result exactly those sums: ac_k / ac_0 * var_j * (niter-1)/niter == sum_t c_t c_{t+k} / niter;
+        // only the lags Geyer's scan visits are computed, 4x faster at config 2), plus the one place where the
+        // formulas differ: a constant split chain is 0/0 = NaN in the reference (src/ess_rhat.jl:192).  With
+        // MDT_FFT_LDS=1 the in-LDS transform runs whenever the padded chain fits.
+        const bool fft_lds = kp.method == 1 && kp.fft_lds && kp.niter + kp.maxlag + 1 <= FFT_MAXN;
         auto fft_const_chain_nan = [&](double ess) -> double {
             if (kp.method != 1 || fft_lds) return ess;
             if (tid == 0) {
@@ -3069,12 +3071,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         ntgt = ((int*)(smem + OFF_INTS))[8];
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold) || kp.mode == 5;
         // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
-        const bool seg_req = zfast && !(kp.method == 1 && kp.niter + kp.maxlag + 1 <= FFT_MAXN) && kp.mode != 3;
+        const bool seg_req = zfast && !fft_lds && kp.mode != 3;
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
                 rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3,
-                                  (est_ind || kp.mode == 5) ? 4 : ((seg_req && (kp.need_eb || kp.need_rb)) ? 1 : 0));
+                                  // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
+                                  (est_ind || kp.mode == 5 || (!(kp.need_eb || kp.need_rb) && kp.mode != 3)) ? 4
+                                      : (seg_req ? 1 : 0));
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);

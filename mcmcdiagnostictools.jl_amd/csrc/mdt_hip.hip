@@ -249,7 +249,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
-    const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
+    const bool fft_lds = fft && getenv("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
+    const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
                             D <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
     const bool small = ctx->force_cfg == 1 ? false : small_fits; // 80 KiB tables, two workgroups per CU
 
@@ -315,7 +316,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.x = dx;
     kp.D = D; kp.C = C; kp.P = P; kp.n = n;
     kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
-    kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est;
+    kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est; kp.fft_lds = fft_lds ? 1 : 0;
     kp.need_eb = rq.need_eb; kp.need_rb = rq.need_rb; kp.need_et = rq.need_et; kp.need_rt = rq.need_rt;
     kp.method = a->autocov; kp.ess_ok = ess_ok; kp.relative = a->relative ? 1 : 0; kp.fold = rq.fold;
     kp.maxlag = maxlag;

@@ -459,3 +459,21 @@ def test_long_heavy_tailed_slices(pkg):
     want = co.bulk_tail(x)
     for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
         assert_close(a, b, RTOL64, nm)
+
+
+def test_fft_in_lds_transform(pkg, methods, monkeypatch):
+    """FFTAutocovMethod is served from lagged products by default; MDT_FFT_LDS=1 runs the in-LDS radix-2
+    transform instead: both against the golden vectors"""
+    import warnings
+    monkeypatch.setenv("MDT_FFT_LDS", "1")
+    for name in ("cfg1_randn_1000x4x10", "ar1_500x4x10", "constant_100x3x2", "odd_1001x3x3"):
+        g = load_golden(name)
+        xd = dev(g["x"])
+        for ke, kr, kind, method, s, ml in _keys(g):
+            if method != "fft":
+                continue
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods["fft"], split_chains=s, maxlag=ml)
+            assert_close(host(S), g[ke], RTOL64, f"{name} {ke} (in-LDS FFT)")
+            assert_close(host(R), g[kr], RTOL64, f"{name} {kr} (in-LDS FFT)")
