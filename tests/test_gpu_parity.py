@@ -477,3 +477,40 @@ def test_fft_in_lds_transform(pkg, methods, monkeypatch):
                 S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods["fft"], split_chains=s, maxlag=ml)
             assert_close(host(S), g[ke], RTOL64, f"{name} {ke} (in-LDS FFT)")
             assert_close(host(R), g[kr], RTOL64, f"{name} {kr} (in-LDS FFT)")
+
+
+def test_fuzz_kwargs_f32_nested(pkg, methods):
+    """seeded random keyword combinations (relative, tail_prob, maxlag), Float32 inputs and nested R-hat"""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(777)
+    for it in range(24):
+        D = int(rng.integers(12, 1500))
+        K, S = int(rng.integers(1, 4)), int(rng.integers(2, 4))
+        C = K * S
+        P = int(rng.integers(1, 4))
+        s = int(rng.integers(1, 3))
+        f32 = it % 3 == 0
+        x = ar1(float(rng.uniform(-0.5, 0.9)), D, C, P, rng) + 0.3 * rng.standard_normal((1, C, 1))
+        if f32:
+            x = x.astype(np.float32)
+        tol = 1e-6 if f32 else 1e-8
+        tp = float(rng.choice([0.02, 0.1, 0.3, 0.5]))
+        rel = bool(it % 2)
+        ml = int(rng.choice([2, 7, 100, 250]))
+        m = ("direct", "fft", "bda")[it % 3]
+        xd = dev(x)
+        what = f"it={it} D={D} C={C} P={P} s={s} f32={f32} tp={tp} rel={rel} ml={ml} {m}"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = [host(o) for o in pkg.bulk_tail(xd, relative=rel, autocov_method=methods[m], split_chains=s, maxlag=ml, tail_prob=tp)]
+            want = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml, relative=rel, tail_prob=tp)
+            for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+                assert_close(a, b, tol, what + " " + nm)
+            ids = np.repeat(np.arange(1, S + 1), K)
+            inds = np.arange(C, dtype=np.int32).reshape(K, S, order="F")
+            for kind in KINDS:
+                assert_close(host(pkg.rhat_nested(xd, ids, kind=kind, split_chains=s)),
+                             co.rhat_nested(x, inds, kind=kind, split_chains=s), tol, what + " nested " + kind)
+            assert_close(host(pkg.mcse(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)),
+                         co.mcse_mean(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse")
