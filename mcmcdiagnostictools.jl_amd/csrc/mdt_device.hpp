@@ -2132,11 +2132,21 @@ constexpr int OFF_ZK = OFF_ZEDGE + 3 * 2 * SZ_EDGE * 8;        // double zk[4]
 constexpr int LDS_ZSER_END = OFF_ZK + 4 * 8;
 static_assert(LDS_ZSER_END <= LDS_BYTES, "z-series view exceeds the LDS carve");
 
-template <bool SEG>
-MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsigned short* loc_, bool want_acov_, unsigned char* smem) {
+// RAW = true: the series are raw draws of type XT in time order (kind = :basic, mcse): values are unbounded, so the
+//   moments are plain double sums, taken by 1024 virtual threads (a 512-thread workgroup plays two each) and
+//   reduced in a fixed order -- the same bits in every geometry.  They always come from the streaming branch
+//   (want_acov = false); the autocovariance sweep then takes mean_j / var_j as given, like series_phase does.
+constexpr int VT = 1024;                  // virtual threads of the raw-draw moment sums
+constexpr int NV = VT / NT;               // virtual threads per thread
+constexpr int VW = VT / 64;               // virtual waves = moment partials per chain
+constexpr int ZMB = 16;                   // chains per batch of the raw-draw moment sweep
+static_assert(ZMB * VW * 2 * 8 + ZMB * 8 <= 3 * NLAGTAB * 8, "raw-draw moment partials must fit the lag tables");
+template <bool SEG, bool RAW = false, typename XT = double>
+MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const XT* z_, const unsigned short* loc_, bool want_acov_, unsigned char* smem) {
+    static_assert(!(SEG && RAW), "raw draws are never in segment order");
     const MDT_CA KP& kp = MDT_UNIFORM_KP(kp_);
     const bool want_acov = uni(want_acov_);
-    const MDT_GA double* z = uniptr_g(z_);
+    const MDT_GA XT* z = uniptr_g(z_);
     const MDT_GA unsigned short* locs = uniptr_g(loc_);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     double* scal = (double*)(smem + OFF_SCAL);
@@ -2167,8 +2177,62 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
         // (a vector load on purpose: the scalar cache is not coherent with the stores of the rank phase)
         int zero = 0;
         asm volatile("" : "+v"(zero));
-        return z[chain_e0(j) + zero];
+        return (double)z[chain_e0(j) + zero];
     };
+
+    if (!want_acov && RAW) {
+        // ---- moments only, raw draws: per virtual thread sums of u = x - K_j and u^2, fixed-order reduction
+        double* zmom = (double*)(smem + OFF_ZS1);     // [ZMB][VW][2]
+        double* Kt = zmom + ZMB * VW * 2;             // [ZMB]
+        constexpr int SU = 8;                         // loads in flight per thread (a multiple of NV)
+        static_assert(SU % NV == 0, "virtual-thread bookkeeping");
+        for (int jb = 0; jb < m; jb += ZMB) {
+            const int nb = (m - jb < ZMB) ? m - jb : ZMB;
+            for (int jl = 0; jl < nb; ++jl) {
+                const int j = jb + jl;
+                const double Kj = chain_K(j);
+                const MDT_GA XT* zc = z + chain_e0(j);
+                double s1[NV], s2[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q) { s1[q] = 0.0; s2[q] = 0.0; }
+                for (int i0 = 0; i0 < n; i0 += NT * SU) {
+                    double vv[SU];
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) {
+                        const int i = i0 + u * NT + tid;
+                        vv[u] = (i < n) ? (double)zc[i] : Kj;
+                    }
+#pragma unroll
+                    for (int u = 0; u < SU; ++u) { // element i belongs to virtual thread i mod 1024 = (u mod NV) * NT + tid
+                        const double uu = vv[u] - Kj; // exactly 0 for the padding lanes
+                        s1[u % NV] += uu;
+                        s2[u % NV] = fma(uu, uu, s2[u % NV]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NV; ++q) {
+                    const double r1 = wave_sum(s1[q]), r2 = wave_sum(s2[q]);
+                    if (lane == 0) { zmom[(jl * VW + q * NWAVE + w) * 2] = r1; zmom[(jl * VW + q * NWAVE + w) * 2 + 1] = r2; }
+                }
+                if (tid == 0) Kt[jl] = Kj;
+            }
+            __syncthreads();
+            if (tid < nb) {
+                double S1 = 0.0, S2 = 0.0;
+                for (int q = 0; q < VW; ++q) { S1 += zmom[(tid * VW + q) * 2]; S2 += zmom[(tid * VW + q) * 2 + 1]; }
+                const double mu = S1 / (double)n;
+                mean_j[jb + tid] = Kt[tid] + mu;
+                var_j[jb + tid] = (S2 - mu * S1) / (double)(n - 1);
+            }
+            __syncthreads();
+        }
+        if (tid == 0) series_combine(kp, smem, 0, 1, false);
+        __syncthreads();
+        out.rhat = scal[2];
+        out.ess = __builtin_nan("");
+        __syncthreads();
+        return out;
+    }
 
     if (!want_acov) {
         // ---- moments only: stream every chain once, integer sums, one LDS atomic per wave and chain
@@ -2180,14 +2244,14 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
         constexpr int SU = 8; // loads in flight per thread
         for (int j = 0; j < m; ++j) {
             const double Kj = chain_K(j);
-            const MDT_GA double* zc = z + (SEG ? (long long)j * niter : chain_e0(j));
+            const MDT_GA XT* zc = z + (SEG ? (long long)j * niter : chain_e0(j));
             long long a1 = 0, a2 = 0;
             for (int i0 = 0; i0 < n; i0 += NT * SU) {
                 double vv[SU];
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
                     const int i = i0 + u * NT + tid;
-                    vv[u] = (i < n) ? zc[i] : Kj;
+                    vv[u] = (i < n) ? (double)zc[i] : Kj;
                 }
 #pragma unroll
                 for (int u = 0; u < SU; ++u) {
@@ -2225,20 +2289,20 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
     double Kj = 0.0;
     auto issue_loads = [&](int j) {
         if (SEG) {
-            const MDT_GA double* zc = z + (long long)j * niter;
+            const MDT_GA XT* zc = z + (long long)j * niter;
             const MDT_GA unsigned short* lc = locs + (long long)j * niter;
 #pragma unroll
             for (int u = 0; u < LD; ++u) {
                 const int i = u * NT + tid;
-                v[u] = (i < n) ? zc[i] : 0.0;
+                v[u] = (i < n) ? (double)zc[i] : 0.0;
                 loc[u] = (i < n) ? (int)lc[i] : i;
             }
         } else {
-            const MDT_GA double* zc = z + chain_e0(j);
+            const MDT_GA XT* zc = z + chain_e0(j);
 #pragma unroll
             for (int u = 0; u < LD; ++u) {
                 const int i = u * NT + tid;
-                v[u] = (i < n) ? zc[i] : 0.0;
+                v[u] = (i < n) ? (double)zc[i] : 0.0;
                 loc[u] = i;
             }
         }
@@ -2277,10 +2341,17 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
             const double* eh = zedge + b3 * 2 * SZ_EDGE;
             const double* et = eh + SZ_EDGE;
             const long long kq = k0 + lane;
-            // S1, S2: exact integer sums of the wave partials
-            const double S1 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 8 + lane] : 0) * fx.i1;
-            const double S2 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 9 + lane] : 0) * fx.i2;
-            const double mu = S1 / (double)n;
+            // S1, S2: exact integer sums of the wave partials (raw draws: from the given mean_j / var_j)
+            double S1, S2, mu;
+            if (RAW) {
+                mu = mean_j[j] - zk[b3];
+                S1 = (double)n * mu;
+                S2 = var_j[j] * (double)(n - 1) + mu * S1;
+            } else {
+                S1 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 8 + lane] : 0) * fx.i1;
+                S2 = (double)wave_sum_i64((lane < NWAVE) ? ppi[NWAVE * 9 + lane] : 0) * fx.i2;
+                mu = S1 / (double)n;
+            }
             // head_k = sum_{t<k} u_t, tail_k = sum of the last k values (k clamped to the kept edge):
             // totals of the 64-wide chunks below k0, then an exclusive scan inside [k0, k0+64)
             double ch = 0.0, ct = 0.0, chq = 0.0, ctq = 0.0;
@@ -2303,9 +2374,11 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
             if (lane < 8 * G && kq < kend) {
                 const int kk2 = (int)kq < he ? (int)kq : he;
                 if (kq == 0) {
-                    const double C = S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
-                    var_j[j] = C / (double)(n - 1);
-                    mean_j[j] = zk[b3] + mu;
+                    const double C = RAW ? var_j[j] * (double)(n - 1) : S2 - mu * S1; // same expression as the moments-only path: bit-identical R-hat
+                    if (!RAW) {
+                        var_j[j] = C / (double)(n - 1);
+                        mean_j[j] = zk[b3] + mu;
+                    }
                     corr += C;
                 } else {
                     corr += (double)(n - kq) * mu * mu - mu * ((S1 - tail) + (S1 - head));
@@ -2338,15 +2411,16 @@ MDT_PHASE SeriesOut series_z_phase(const KP& kp_, const double* z_, const unsign
                     buf[l] = uu;
                     if (l < he) eh[l] = uu;
                     if (l >= n - he) et[l - (n - he)] = uu;
-                    a1 += fx.u(uu);
-                    a2 += fx.uu(uu * uu);
+                    if (!RAW) { a1 += fx.u(uu); a2 += fx.uu(uu * uu); }
                 } else if (i < n + halo) {
                     buf[i] = 0.0;
                 }
             }
-            a1 = wave_sum_i64(a1);
-            a2 = wave_sum_i64(a2);
-            if (lane == 0) { ((long long*)pp)[NWAVE * 8 + w] = a1; ((long long*)pp)[NWAVE * 9 + w] = a2; }
+            if (!RAW) {
+                a1 = wave_sum_i64(a1);
+                a2 = wave_sum_i64(a2);
+                if (lane == 0) { ((long long*)pp)[NWAVE * 8 + w] = a1; ((long long*)pp)[NWAVE * 9 + w] = a2; }
+            }
             if (tid == 0) zk[b3] = Kj;
             MDT_PROF_ZMARK(13); // waiting for the loads + LDS stores + moments
             __syncthreads();
@@ -3021,8 +3095,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
 
         if (kp.basic && kp.mode != 3) {
+            // raw draws: moments (and R-hat) from the streaming sweep of series_z_phase<RAW>, whatever follows --
+            // rhat(x) and ess_rhat(x).rhat are the same bits; then the autocovariance: the in-LDS FFT if asked
+            // for, the one-chain-per-LDS-buffer sweep when a split chain fits, the tiled series_phase otherwise
             const bool acov = kp.need_eb && kp.ess_ok;
-            const SeriesOut so = basic_ess_rhat(YX, acov);
+            SeriesOut so = series_z_phase<false, true, T>(kp, xp, nullptr, false, smem);
+            if (acov) {
+                SeriesOut sa;
+                if (fft_lds) sa = series_fft_phase(kp, YX, smem);
+                else if (zfast) sa = series_z_phase<false, true, T>(kp, xp, nullptr, true, smem);
+                else sa = series_phase(kp, YX, true, smem, true);
+                so.ess = fft_lds ? sa.ess : fft_const_chain_nan(sa.ess);
+            }
             double ess = acov ? so.ess : nan;
             if (kp.mode == 1) {
                 if (tid == 0) store_out<T>(kp.out_rb, p, nested_combine());
