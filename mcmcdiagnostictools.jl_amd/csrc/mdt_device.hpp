@@ -3162,7 +3162,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3,
                                   // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
                                   (est_ind || kp.mode == 5 || (!(kp.need_eb || kp.need_rb) && kp.mode != 3)) ? 4
-                                      : (seg_req ? 1 : 0));
+                                      // nested R-hat only needs the moments (and has no ess_rhat twin whose bits it must match)
+                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : 0)));
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
@@ -3255,7 +3256,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             SeriesOut so;
             // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
             // bits whichever autocovariance path follows
-            if (acov && fft_lds) {
+            if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat)
+                so.rhat = nan; so.ess = nan;
+            } else if (acov && fft_lds) {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_fft_phase(kp, YZ, smem);
             } else if (zfast || !acov) {
