@@ -443,7 +443,7 @@ __device__ inline int wg_sample_rank(double& v, double* buf) {
 }
 
 // Splitter search seeded by a uniform grid: cell(v) is monotone in v, and lut[cell] brackets the
-// coarse index (see build in rank_phase_reg), so the search usually needs 0-1 steps instead of 8.
+// coarse index (built in the sample step of the rank phases), so the search usually needs 0-2 steps instead of 8.
 struct BinCtx {
     double t0, top, ginv;
 };
