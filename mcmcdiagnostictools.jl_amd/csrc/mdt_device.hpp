@@ -95,7 +95,8 @@ constexpr int OFF_SBITS = OFF_BITS + 2 * BITW * 8;        // uint64 sbits[2][BIT
 constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
 constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})
 constexpr int OFF_IVAR = OFF_IDIF + 2 * NLAGTAB * 8;      // double imean[2][MAXM]
-constexpr int LDS_IND_END = OFF_IVAR + 2 * MAXM * 8;
+constexpr int OFF_IPART = OFF_IVAR + 2 * MAXM * 8;         // int ipart[2][NWAVE/2][64][2]: (S, A_k) of a word segment
+constexpr int LDS_IND_END = OFF_IPART + 2 * (NWAVE / 2) * 64 * 2 * 4;
 constexpr int LDS_BYTES = MDT_LDS_LIMIT; // 160 KiB per CU on gfx950: one big or two small workgroups
 static_assert(LDS_RANK_END <= LDS_BYTES && LDS_SER_END <= LDS_BYTES && LDS_IND_END <= LDS_BYTES, "LDS budget");
 
@@ -2643,23 +2644,57 @@ MDT_PHASE double indicator_phase(const KP& kp_, const T* xp_, double qlo_, doubl
                     sbits[ind * BITW + wi] = v;
                 }
                 __syncthreads();
-                // wave -> (indicator, lag); lanes own lags
-                if (w < 2) {
-                    const int ind = w;
+                // wave -> (indicator, word segment); lanes own lags.  Only A_k = sum_t I_t I_{t+k} walks the chain per lag
+                // (S is the same for every lag, T_k and H_k are S minus a few leading / trailing words).
+                {
+                    const int ind = w & 1, seg = w >> 1;
+                    constexpr int NSEG = NWAVE / 2;
                     const unsigned long long* sb = sbits + ind * BITW;
                     const long long k = k0 + lane;
-                    long long Sx = 0, Ak = 0, Hk = 0, Tk = 0;
+                    const int wq = (nwS + NSEG - 1) / NSEG, i0 = seg * wq, i1 = (i0 + wq < nwS) ? i0 + wq : nwS;
+                    int sxp = 0, akp = 0;
                     if (k < kend) {
-                        for (int i = 0; i < nwS; ++i) {
+                        const int q = (int)(k >> 6), r = (int)(k & 63);
+                        unsigned long long lo = (i0 + q < nwS) ? sb[i0 + q] : 0ull;
+                        for (int i = i0; i < i1; ++i) {
                             const unsigned long long v = sb[i];
-                            const unsigned long long vs = bits_at(sb, ((long long)i << 6) + k, nwS);
-                            long long cnt = niter - (((long long)i << 6) + k); // positions t+k < niter
-                            const unsigned long long ms = cnt >= 64 ? ~0ull : (cnt <= 0 ? 0ull : ((1ull << cnt) - 1ull));
-                            Sx += __popcll(v);
-                            Ak += __popcll(v & vs);
-                            Tk += __popcll(vs);
-                            Hk += __popcll(v & ms);
+                            const unsigned long long hi = (i + q + 1 < nwS) ? sb[i + q + 1] : 0ull;
+                            const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
+                            sxp += __popcll(v);
+                            akp += __popcll(v & vs);
+                            lo = hi;
                         }
+                    }
+                    int* ipart = (int*)(smem + OFF_IPART);
+                    ipart[((ind * NSEG + seg) * 64 + lane) * 2] = sxp;
+                    ipart[((ind * NSEG + seg) * 64 + lane) * 2 + 1] = akp;
+                }
+                __syncthreads();
+                if (w < 2) {
+                    const int ind = w;
+                    constexpr int NSEG = NWAVE / 2;
+                    const unsigned long long* sb = sbits + ind * BITW;
+                    const int* ipart = (const int*)(smem + OFF_IPART);
+                    const long long k = k0 + lane;
+                    if (k < kend) {
+                        long long Sx = 0, Ak = 0;
+                        for (int sg = 0; sg < NSEG; ++sg) { Sx += ipart[((ind * NSEG + sg) * 64 + lane) * 2]; Ak += ipart[((ind * NSEG + sg) * 64 + lane) * 2 + 1]; }
+                        const int q = (int)(k >> 6);
+                        long long head = 0, tail = 0; // ones among the first k / the last k positions
+                        for (int i = 0; i <= q && i < nwS; ++i) {
+                            const long long nb2 = k - ((long long)i << 6);
+                            const unsigned long long mk = nb2 >= 64 ? ~0ull : (nb2 <= 0 ? 0ull : ((1ull << nb2) - 1ull));
+                            head += __popcll(sb[i] & mk);
+                        }
+                        {
+                            const long long p0 = niter - k;
+                            for (int i = (int)((p0 > 0 ? p0 : 0) >> 6); i < nwS; ++i) {
+                                const long long sk = p0 - ((long long)i << 6);
+                                const unsigned long long mk = sk <= 0 ? ~0ull : (sk >= 64 ? 0ull : ~((1ull << sk) - 1ull));
+                                tail += __popcll(sb[i] & mk);
+                            }
+                        }
+                        const long long Tk = Sx - head, Hk = Sx - tail;
                         // n^2 * sum_t (I_t - mu)(I_{t+k} - mu) with mu = S/n, exact in int64
                         const long long N = niter * niter * Ak - niter * Sx * (Hk + Tk) + (niter - k) * Sx * Sx;
                         double ck = (double)N / (dn * dn);
