@@ -154,7 +154,8 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"ess_rhat bulk+tail, {D} draws x {C} chains x {P} params Float64 per GPU "
-                            "(BASELINE.json configs[1]); half IID N(0,1), half AR(1) phi in (-0.3,0.3,0.7,0.9)",
+                            + ("(BASELINE.json configs[1])" if (D, C, P) == (10000, 4, 10000) else "(non-default shape)")
+                            + "; half IID N(0,1), half AR(1) phi in (-0.3,0.3,0.7,0.9)",
                 "draws": D, "chains": C, "params_per_gpu": P, "autocov_method": type(method).__name__,
                 "split_chains": 2, "maxlag": 250, "tail_prob": 0.1, "sharding": f"params axis x{world}",
             },

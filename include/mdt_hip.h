@@ -143,6 +143,24 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* args, const void* x, void* m
 int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* args, const void* x_dpc, void* x_dcp);
 
 /*
+ * bfmi(energy; dims = 1) -- replaces src/bfmi.jl:38-45: per chain,
+ * mean(abs2, diff(energy)) / var(energy).  energy is (draws, chains[, params]) column-major; one value per
+ * column, bfmi_out[chains*params] in dtype.  One streaming pass (plus an L2-resident second pass for the
+ * centred sum).  args: draws, chains, params, dtype, location, stream, sync.
+ */
+int mdt_bfmi(mdt_ctx* ctx, const mdt_args* args, const void* energy, void* bfmi_out);
+
+/*
+ * gelmandiag(samples; alpha) -- replaces the univariate parts of src/gelmandiag.jl:1-60, 76-80: the potential
+ * scale reduction factor and its upper (1 - alpha/2) confidence limit per parameter.  One streaming pass for the
+ * per-chain means and variances, then one thread per parameter for the few flops that follow and the
+ * F-distribution quantile (Distributions.quantile(FDist(...)), :50); nothing runs on the host.  psrf / psrfci:
+ * [params] Float64 whatever the input dtype (:41-42), host or device per args->location.  chains < 2 -> MDT_EARG
+ * (:3).  gelmandiag_multivariate (:86-113, a params x params eigenproblem) is not provided.
+ */
+int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* args, const void* x, double alpha, double* psrf, double* psrfci);
+
+/*
  * Stage output for parity checks: _rank_normalize (src/utils.jl:169-184) of x (or, with
  * fold != 0, of _fold_around_median(x), :148-158).  rank_out: [draws*chains*params] float64
  * tied ranks (StatsBase.tiedrank) or NULL; z_out: same length, dtype, normal scores, or NULL.

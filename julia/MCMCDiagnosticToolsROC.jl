@@ -8,7 +8,7 @@ module MCMCDiagnosticToolsROC
 
 using Statistics: Statistics
 
-export ess, rhat, ess_rhat, rhat_nested, mcse
+export ess, rhat, ess_rhat, rhat_nested, mcse, bfmi, gelmandiag
 export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
 
 const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")
@@ -161,6 +161,33 @@ function mcse(x::AbstractArray{<:Real}; kind=Statistics.mean, autocov_method=Aut
         end
     end
     return _out(x, out)
+end
+
+# bfmi(energy; dims = 1) (src/bfmi.jl:38-45): one value per chain
+function bfmi(energy::AbstractVector{<:Real})
+    return bfmi(reshape(energy, :, 1))[1]
+end
+function bfmi(energy::AbstractMatrix{<:Real}; dims::Int=1)
+    e = dims == 1 ? energy : permutedims(energy)
+    T = float(eltype(e)); T in (Float32, Float64) || (T = Float64)
+    e2 = convert(Matrix{T}, e)
+    D, C = size(e2)
+    out = Vector{T}(undef, C)
+    a = MdtArgs(D, C, 1, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
+    GC.@preserve e2 out _check(ccall((:mdt_bfmi, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, e2, out))
+    return out
+end
+
+# gelmandiag(samples; alpha) (src/gelmandiag.jl:76-80); Float64 results whatever the eltype (:41-42)
+function gelmandiag(chains::AbstractArray{<:Real,3}; alpha::Real=0.05)
+    size(chains, 2) > 1 || error("Gelman diagnostic requires at least 2 chains")  # :3
+    T, x3 = _params_array(chains)
+    D, C, P = size(x3)
+    psrf, psrfci = Vector{Float64}(undef, P), Vector{Float64}(undef, P)
+    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
+    GC.@preserve x3 psrf psrfci _check(ccall((:mdt_gelmandiag, libmdt), Cint,
+        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}), ctx(), a, x3, Float64(alpha), psrf, psrfci))
+    return (psrf=psrf, psrfci=psrfci)
 end
 
 end # module

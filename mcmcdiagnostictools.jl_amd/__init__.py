@@ -9,13 +9,17 @@ from .api import (  # noqa: F401
     AbstractAutocovMethod,
     AutocovMethod,
     BDAAutocovMethod,
+    ErrorException,
     ESSRhat,
     FFTAutocovMethod,
+    GelmanDiag,
     Quantile,
+    bfmi,
     bulk_tail,
     ess,
     ess_rhat,
     from_mcmcchains_layout,
+    gelmandiag,
     mcse,
     rank_normalize,
     rhat,

@@ -402,3 +402,53 @@ def from_mcmcchains_layout(samples):
     rc = _lib.load().mdt_layout_from_dpc(h, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
     _lib.check(rc, h)
     return out.permute(2, 1, 0)
+
+
+class ErrorException(RuntimeError):
+    """Julia's ErrorException (`error("...")`), src/gelmandiag.jl:3"""
+
+
+GelmanDiag = namedtuple("GelmanDiag", ["psrf", "psrfci"])
+
+
+def bfmi(energy, *, dims=1):
+    """Estimated Bayesian fraction of missing information (src/bfmi.jl:38-45): per chain,
+    mean(abs2, diff(energy)) / var(energy).  `energy` is a vector of draws (-> a scalar) or a matrix;
+    `dims` is the axis holding the draws in the reference's 1-based numbering (default 1: (draws, chains))."""
+    is_torch = torch is not None and isinstance(energy, torch.Tensor)
+    e = energy if is_torch else np.asarray(energy)
+    if e.ndim == 1:
+        e2 = e.reshape(-1, 1)
+    elif e.ndim == 2:
+        if dims not in (1, 2):
+            raise ArgumentError("dims must be 1 or 2 for a matrix of energies")
+        e2 = e if dims == 1 else (e.t() if is_torch else e.T)
+    else:
+        raise ArgumentError("`energy` must be a vector or a matrix")  # MethodError in the reference
+    pr = _prepare(e2)
+    out = _new_out(pr, pr.C)
+    if pr.C > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
+        rc = _lib.load().mdt_bfmi(h, ctypes.byref(a), pr.ptr, _optr(out))
+        _lib.check(rc, h)
+    return float(out[0]) if e.ndim == 1 else out
+
+
+def gelmandiag(samples, *, alpha=0.05):
+    """Gelman, Rubin and Brooks diagnostic (src/gelmandiag.jl:76-80): (psrf, psrfci) per parameter for
+    `samples` of shape (draws, chains, parameters); both Float64 (:41-42).  The multivariate variant is not
+    provided."""
+    if getattr(samples, "ndim", np.ndim(samples)) != 3:
+        raise ArgumentError("`samples` must have shape (draws, chains, parameters)")  # MethodError in the reference
+    pr = _prepare(samples)
+    if pr.C < 2:
+        raise ErrorException("Gelman diagnostic requires at least 2 chains")
+    f64 = torch.float64 if pr.torch else np.float64
+    psrf, ci = _new_out(pr, pr.P, f64), _new_out(pr, pr.P, f64)
+    if pr.P > 0:
+        h = _lib.ctx(pr.device_index)
+        a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
+        rc = _lib.load().mdt_gelmandiag(h, ctypes.byref(a), pr.ptr, float(alpha), _optr(psrf), _optr(ci))
+        _lib.check(rc, h)
+    return GelmanDiag(psrf, ci)

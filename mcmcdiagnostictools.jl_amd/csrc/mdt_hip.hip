@@ -37,6 +37,7 @@
 #include <cstring>
 #include <new>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -72,6 +73,9 @@ struct mdt_ctx {
     void* ess_tmp = nullptr;
     unsigned int* tpos_arr = nullptr;
     long long mq_cap = 0;
+    // bfmi / gelmandiag: (mean, variance, mean squared difference) of every column
+    double* mom = nullptr;
+    long long mom_cap = 0;
     // host staging
     void* stage_x = nullptr;
     size_t stage_x_cap = 0;
@@ -92,9 +96,62 @@ __global__ void permute_dpc_kernel(const T* __restrict__ in, T* __restrict__ out
 }
 
 
+// One workgroup per column of `draws` contiguous values: mean, corrected variance (two passes, the second one
+// re-reads the column from L2) and the mean squared first difference.  mom[3 * col + {0, 1, 2}].
+// Streaming, HBM-bound: draws * sizeof(T) algorithmic bytes per column.  (src/bfmi.jl:38-45, gelmandiag.jl:10-13)
+template <typename T>
+__global__ __launch_bounds__(256) void column_moments_kernel(const T* __restrict__ x, long long D, long long ncol,
+                                                             double* __restrict__ mom, T* __restrict__ bfmi_out) {
+    __shared__ double red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    auto wave_sum = [](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    };
+    for (long long col = blockIdx.x; col < ncol; col += gridDim.x) {
+        const T* xc = x + col * D;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        long long d = tid;
+        for (; d + 768 < D; d += 1024) {
+            const double a0 = (double)xc[d], a1 = (double)xc[d + 256], a2 = (double)xc[d + 512], a3 = (double)xc[d + 768];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; d < D; d += 256) s0 += (double)xc[d];
+        const double ws = wave_sum((s0 + s1) + (s2 + s3));
+        if (lane == 0) red[0][w] = ws;
+        __syncthreads();
+        const double mu = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double)D;
+        double v0 = 0, v1 = 0, q0 = 0, q1 = 0;
+        d = tid;
+        for (; d + 256 < D; d += 512) {
+            const double a0 = (double)xc[d], b0 = (double)xc[d + 1], a1 = (double)xc[d + 256];
+            const double b1 = (d + 257 < D) ? (double)xc[d + 257] : a1;
+            v0 += (a0 - mu) * (a0 - mu); v1 += (a1 - mu) * (a1 - mu);
+            q0 += (b0 - a0) * (b0 - a0); q1 += (b1 - a1) * (b1 - a1);
+        }
+        for (; d < D; d += 256) {
+            const double a0 = (double)xc[d], b0 = (d + 1 < D) ? (double)xc[d + 1] : a0;
+            v0 += (a0 - mu) * (a0 - mu);
+            q0 += (b0 - a0) * (b0 - a0);
+        }
+        const double wv = wave_sum(v0 + v1), wq = wave_sum(q0 + q1);
+        if (lane == 0) { red[1][w] = wv; red[2][w] = wq; }
+        __syncthreads();
+        if (tid == 0) {
+            const double dm1 = (double)(D - 1);
+            const double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / dm1;
+            const double msd = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / dm1;
+            if (bfmi_out) bfmi_out[col] = (T)(msd / var); // mean(abs2, diff(energy)) / var(energy), src/bfmi.jl:39
+            else { mom[3 * col] = mu; mom[3 * col + 1] = var; mom[3 * col + 2] = msd; }
+        }
+        __syncthreads();
+    }
+}
+
 /* Regularised incomplete beta I_x(a, b) (continued fraction, modified Lentz) and its inverse (safeguarded
  * Newton): StatsFuns.betainvcdf of src/mcse.jl:105-106.  Agrees with scipy.special.betaincinv to ~1e-11. */
-static double mdt_betacf(double a, double b, double x) {
+__host__ __device__ static double mdt_betacf(double a, double b, double x) {
     const double qab = a + b, qap = a + 1.0, qam = a - 1.0, tiny = 1e-300;
     double c = 1.0, d = 1.0 - qab * x / qap;
     if (fabs(d) < tiny) d = tiny;
@@ -116,7 +173,7 @@ static double mdt_betacf(double a, double b, double x) {
     }
     return h;
 }
-static double mdt_ibeta(double a, double b, double x) {
+__host__ __device__ static double mdt_ibeta(double a, double b, double x) {
     if (x <= 0.0) return 0.0;
     if (x >= 1.0) return 1.0;
     const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
@@ -124,7 +181,7 @@ static double mdt_ibeta(double a, double b, double x) {
     if (x < (a + 1.0) / (a + b + 2.0)) return bt * mdt_betacf(a, b, x) / a;
     return 1.0 - bt * mdt_betacf(b, a, 1.0 - x) / b;
 }
-static double mdt_betainvcdf(double a, double b, double p) {
+__host__ __device__ static double mdt_betainvcdf(double a, double b, double p) {
     double lo = 0.0, hi = 1.0, x = a / (a + b);
     { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
         const double sd = sqrt(a * b / ((a + b) * (a + b) * (a + b + 1.0)));
@@ -143,6 +200,46 @@ static double mdt_betainvcdf(double a, double b, double p) {
         x = xn;
     }
     return x;
+}
+
+// One thread per parameter: the flops that follow the per-chain moments (src/gelmandiag.jl:5-57, the diagonal
+// entries only) and the F quantile of :50, quantile(FDist(d1, d2), q) = d2 y / (d1 (1 - y)) with
+// y = betainvcdf(d1/2, d2/2, q).  All Float64 (:41-42).  status |= 4 when FDist would reject its parameter.
+__global__ __launch_bounds__(64) void gelman_finish_kernel(const double* __restrict__ mom, long long D, long long C, long long P,
+                                                           double alpha, double* __restrict__ psrf, double* __restrict__ psrfci,
+                                                           int* __restrict__ status) {
+    const long long p = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (p >= P) return;
+    const double niters = (double)D, nchains = (double)C;
+    const double rfixed = (niters - 1) / niters, rrandomscale = (nchains + 1) / (nchains * niters);
+    const double q = 1 - alpha / 2, B_df = nchains - 1;
+    const double* mp = mom + 3 * C * p;
+    double w = 0, pbar2 = 0, mq = 0; // means over the chains of s2, psibar, psibar^2
+    for (long long c = 0; c < C; ++c) { pbar2 += mp[3 * c]; w += mp[3 * c + 1]; mq += mp[3 * c] * mp[3 * c]; }
+    w /= nchains; pbar2 /= nchains; mq /= nchains;
+    double bb = 0, vw = 0, c_sq = 0, c_s = 0; // corrected (co)variances over the chains
+    for (long long c = 0; c < C; ++c) {
+        const double dm = mp[3 * c] - pbar2, ds = mp[3 * c + 1] - w;
+        bb += dm * dm; vw += ds * ds;
+        c_sq += ds * (mp[3 * c] * mp[3 * c] - mq);
+        c_s += ds * dm;
+    }
+    const double b = niters * bb / (nchains - 1);
+    const double var_w = vw / (nchains - 1) / nchains;
+    const double var_b = (2 / (nchains - 1)) * b * b;
+    const double var_wb = (niters / nchains) * (c_sq / (nchains - 1) - 2 * pbar2 * (c_s / (nchains - 1)));
+    const double V = rfixed * w + rrandomscale * b;
+    const double var_V = rfixed * rfixed * var_w + rrandomscale * rrandomscale * var_b + 2 * rfixed * rrandomscale * var_wb;
+    const double df = 2 * V * V / var_V, W_df = 2 * w * w / var_w;
+    const double correction = (df + 3) / (df + 1);
+    double rrandom = rrandomscale * b / w;
+    psrf[p] = sqrt(correction * (rfixed + rrandom));
+    if (rrandom == rrandom) {
+        if (!(W_df > 0)) { atomicOr(status, 4); psrfci[p] = __builtin_nan(""); return; }
+        const double y = mdt_betainvcdf(B_df / 2, W_df / 2, q);
+        rrandom *= W_df * y / (B_df * (1 - y));
+    }
+    psrfci[p] = sqrt(correction * (rfixed + rrandom));
 }
 
 constexpr unsigned KP_RING = 64;
@@ -468,6 +565,7 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->tpos_arr) (void)hipFree(ctx->tpos_arr);
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+    if (ctx->mom) (void)hipFree(ctx->mom);
     delete ctx;
     return MDT_OK;
 }
@@ -654,6 +752,114 @@ int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void
                            (long long)a->draws, (long long)a->chains, (long long)a->params);
     HIP_TRY(hipGetLastError());
     if (a->sync) HIP_TRY(hipStreamSynchronize(st));
+    return MDT_OK;
+}
+
+// launches the column pass: (mean, var, msd) of every column into ctx->mom, or bfmi straight into bfmi_dev;
+// x is staged when it lives in host memory
+static int column_moments(mdt_ctx* ctx, const mdt_args* a, const void* x, long long ncol, void* bfmi_dev) {
+    hipStream_t st = (hipStream_t)a->stream;
+    const size_t ts = tsize(a->dtype);
+    const long long D = a->draws;
+    const void* dx = x;
+    if (a->location == MDT_HOST) {
+        const size_t xb = (size_t)D * ncol * ts;
+        if (xb > ctx->stage_x_cap) {
+            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
+            ctx->stage_x_cap = xb;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
+        dx = ctx->stage_x;
+    }
+    if (!bfmi_dev && ncol > ctx->mom_cap) {
+        if (ctx->mom) (void)hipFree(ctx->mom);
+        ctx->mom = nullptr; ctx->mom_cap = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->mom, (size_t)ncol * 3 * sizeof(double)));
+        ctx->mom_cap = ncol;
+    }
+    const unsigned grid = (unsigned)std::min<long long>(ncol, 16LL * (ctx->num_cu > 0 ? ctx->num_cu : 256));
+    if (a->dtype == MDT_F64)
+        hipLaunchKernelGGL(column_moments_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dx, D, ncol, ctx->mom, (double*)bfmi_dev);
+    else
+        hipLaunchKernelGGL(column_moments_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dx, D, ncol, ctx->mom, (float*)bfmi_dev);
+    HIP_TRY(hipGetLastError());
+    return MDT_OK;
+}
+
+static int diag_args_ok(mdt_ctx* ctx, const mdt_args* a) {
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
+    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    return MDT_OK;
+}
+
+// device staging for `bytes` of results of a host-memory request
+static int stage_out_bytes(mdt_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->stage_out_cap) {
+        if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+        ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->stage_out, bytes));
+        ctx->stage_out_cap = bytes;
+    }
+    return MDT_OK;
+}
+
+int mdt_bfmi(mdt_ctx* ctx, const mdt_args* a, const void* energy, void* bfmi_out) {
+    if (!ctx) return MDT_EARG;
+    int rc = diag_args_ok(ctx, a);
+    if (rc) return rc;
+    const long long ncol = a->chains * a->params;
+    if (ncol == 0) return MDT_OK;
+    if (!energy || !bfmi_out) return fail(ctx, MDT_EARG, "NULL pointer");
+    if (a->draws == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)a->stream;
+    const size_t ob = (size_t)ncol * tsize(a->dtype);
+    void* od = bfmi_out;
+    if (a->location == MDT_HOST) {
+        if ((rc = stage_out_bytes(ctx, ob))) return rc;
+        od = ctx->stage_out;
+    }
+    if ((rc = column_moments(ctx, a, energy, ncol, od))) return rc;
+    if (a->location == MDT_HOST) HIP_TRY(hipMemcpyAsync(bfmi_out, od, ob, hipMemcpyDeviceToHost, st));
+    if (a->sync || a->location == MDT_HOST) HIP_TRY(hipStreamSynchronize(st));
+    return MDT_OK;
+}
+
+int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha, double* psrf, double* psrfci) {
+    if (!ctx) return MDT_EARG;
+    int rc = diag_args_ok(ctx, a);
+    if (rc) return rc;
+    const long long D = a->draws, C = a->chains, P = a->params;
+    if (C < 2) return fail(ctx, MDT_EARG, "Gelman diagnostic requires at least 2 chains"); // src/gelmandiag.jl:3
+    if (P == 0) return MDT_OK;
+    if (!x || !psrf || !psrfci) return fail(ctx, MDT_EARG, "NULL pointer");
+    if (D == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)a->stream;
+    double* od0 = psrf; double* od1 = psrfci;
+    if (a->location == MDT_HOST) {
+        if ((rc = stage_out_bytes(ctx, (size_t)P * 16))) return rc;
+        od0 = (double*)ctx->stage_out; od1 = od0 + P;
+    }
+    HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
+    if ((rc = column_moments(ctx, a, x, C * P, nullptr))) return rc;
+    hipLaunchKernelGGL(gelman_finish_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, (const double*)ctx->mom, D, C, P, alpha,
+                       od0, od1, ctx->status);
+    HIP_TRY(hipGetLastError());
+    if (a->location == MDT_HOST) {
+        HIP_TRY(hipMemcpyAsync(psrf, od0, (size_t)P * 8, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(psrfci, od1, (size_t)P * 8, hipMemcpyDeviceToHost, st));
+    }
+    if (a->sync || a->location == MDT_HOST) {
+        int status = 0;
+        HIP_TRY(hipMemcpyAsync(&status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (status & 4) return fail(ctx, MDT_EARG, "FDist: the condition nu2 > zero(nu2) is not satisfied"); // Distributions.FDist
+    }
     return MDT_OK;
 }
 

@@ -176,6 +176,34 @@ def mcse_quantile(x, estimator="median", prob=0.5, autocov="direct", split_chain
     return out
 
 
+def bfmi(energy, faithful=False):
+    """bfmi(energy) for a (draws,) vector or a (draws, chains) matrix, src/bfmi.jl:38-45"""
+    e = np.asarray(energy)
+    if e.dtype not in (np.float32, np.float64):
+        e = e.astype(np.float64)
+    vec = e.ndim == 1
+    e2 = np.asfortranarray(e.reshape(e.shape[0], -1))
+    out = np.empty(e2.shape[1], e2.dtype)
+    f = getattr(lib(), "mdt_oracle_bfmi" + _sfx(e2.dtype, faithful))
+    rc = f(_ptr(e2), ctypes.c_int64(e2.shape[0]), ctypes.c_int64(e2.shape[1]), _ptr(out))
+    if rc:
+        raise OracleError(rc)
+    return out[0] if vec else out
+
+
+def gelmandiag(x, alpha=0.05, faithful=False):
+    """gelmandiag(samples; alpha) -> (psrf, psrfci), both Float64, src/gelmandiag.jl:1-60"""
+    x = _as3d(x)
+    P = x.shape[2]
+    psrf, ci = np.empty(P), np.empty(P)
+    f = getattr(lib(), "mdt_oracle_gelmandiag" + _sfx(x.dtype, faithful))
+    rc = f(_ptr(x), ctypes.c_int64(x.shape[0]), ctypes.c_int64(x.shape[1]), ctypes.c_int64(P), ctypes.c_double(alpha),
+           _ptr(psrf), _ptr(ci))
+    if rc:
+        raise OracleError(rc)
+    return psrf, ci
+
+
 # ---- stage functions (one parameter slice, pooled over draws and chains) ----
 def tiedrank(v):
     v = np.ascontiguousarray(np.asarray(v).ravel(order="F"))

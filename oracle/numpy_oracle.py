@@ -264,3 +264,40 @@ def mcse_quantile(x, estimator="median", prob=0.5, s=2, maxlag=250, method="dire
         lo, up = max(int(np.floor(pl * n)), 1), min(int(np.ceil(pu * n)), n)
         out[q] = (v[up - 1] - v[lo - 1]) / 2
     return out
+
+
+def bfmi(energy):
+    """src/bfmi.jl:38-45"""
+    e = np.asarray(energy, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        return np.mean(np.diff(e, axis=0) ** 2, axis=0) / np.var(e, axis=0, ddof=1)
+
+
+def gelmandiag(x, alpha=0.05):
+    """src/gelmandiag.jl:1-60 (scipy.stats.f.ppf stands in for Distributions.quantile(FDist))."""
+    from scipy.stats import f as fdist
+    x = np.asarray(x, dtype=np.float64)
+    n, m, P = x.shape
+    rfixed, rrs = (n - 1) / n, (m + 1) / (m * n)
+    psibar = x.mean(axis=0)                      # (m, P)
+    s2 = x.var(axis=0, ddof=1)                   # (m, P)
+    w = s2.mean(axis=0)
+    b = n * psibar.var(axis=0, ddof=1)
+    psibar2 = psibar.mean(axis=0)
+
+    def cov(a, c):
+        return ((a - a.mean(axis=0)) * (c - c.mean(axis=0))).sum(axis=0) / (m - 1)
+    with np.errstate(all="ignore"):
+        var_w = s2.var(axis=0, ddof=1) / m
+        var_b = 2 / (m - 1) * b ** 2
+        var_wb = n / m * (cov(s2, psibar ** 2) - 2 * psibar2 * cov(s2, psibar))
+        V = rfixed * w + rrs * b
+        var_V = rfixed ** 2 * var_w + rrs ** 2 * var_b + 2 * rfixed * rrs * var_wb
+        df = 2 * V ** 2 / var_V
+        W_df = 2 * w ** 2 / var_w
+        corr = (df + 3) / (df + 1)
+        rrandom = rrs * b / w
+        psrf = np.sqrt(corr * (rfixed + rrandom))
+        fq = np.where(np.isnan(rrandom), 1.0, fdist.ppf(1 - alpha / 2, m - 1, W_df))
+        ci = np.sqrt(corr * (rfixed + rrandom * fq))
+    return psrf, ci

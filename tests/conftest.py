@@ -16,10 +16,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def golden_names(estimators=False):
-    """fixture names; the est_<name> files (ess(kind = estimator), mcse(std)) share the input of <name>"""
+def golden_names(estimators=False, diag=False):
+    """fixture names; the est_<name> files (ess(kind = estimator), mcse(std)) and the diag_<name> files (bfmi,
+    gelmandiag) share the input of <name>"""
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [n for n in names if n.startswith("est_") == estimators]
+    if diag:
+        return [n for n in names if n.startswith("diag_")]
+    return [n for n in names if not n.startswith("diag_") and n.startswith("est_") == estimators]
 
 
 def load_golden(name):

@@ -194,9 +194,45 @@ def estimators():
     print("wrote", n, "estimator fixtures to", OUT)
 
 
+# the energies of the reference's own known-answer tests (test/bfmi.jl:2-41): data + the expected values there
+BFMI_REF_ENERGY = [42, 44, 45, 46, 42, 43, 36, 36, 31, 36, 36, 32, 36, 31, 31, 29, 29, 30, 25, 26, 29, 29, 27, 30, 31, 29]
+
+
+def diag():
+    """bfmi and gelmandiag on the inputs of existing fixtures: diag_<name>.npz with
+    gelman|<alpha>|psrf, gelman|<alpha>|psrfci and bfmi (every (chain, param) column read as an energy series),
+    plus diag_bfmi_reference.npz = the reference's two known-answer cases."""
+    names = ["cfg1_randn_1000x4x10", "ar1_500x4x10", "ties_200x4x6", "odd_1001x3x3", "f32_300x4x6", "nested_200x16x4"]
+    for name in names:
+        x = np.load(os.path.join(OUT, name + ".npz"))["x"]
+        f32 = x.dtype == np.float32
+        c = {}
+        for alpha in (0.05, 0.2):
+            psrf, ci = co.gelmandiag(x, alpha=alpha)
+            if not f32:
+                a, b = no.gelmandiag(x, alpha=alpha)
+                agree(psrf, a, what=name + " psrf")
+                agree(ci, b, what=name + " psrfci")
+            c[f"gelman|{alpha}|psrf"], c[f"gelman|{alpha}|psrfci"] = psrf, ci
+        e = x.reshape(x.shape[0], -1, order="F")
+        c["bfmi"] = co.bfmi(e)
+        if not f32:
+            agree(c["bfmi"], no.bfmi(e), what=name + " bfmi")
+        np.savez_compressed(os.path.join(OUT, "diag_" + name + ".npz"), **c)
+    e = np.array(BFMI_REF_ENERGY, dtype=np.float64)
+    ref = {"energy_a": np.array([1.0, 2.0, 3.0, 4.0]), "expect_a": np.array(0.6),
+           "energy_b": e, "expect_b": np.array(0.2406937229)}
+    assert abs(co.bfmi(ref["energy_a"]) - 0.6) < 1e-12 and abs(co.bfmi(e) - 0.2406937229) < 1e-9
+    np.savez_compressed(os.path.join(OUT, "diag_bfmi_reference.npz"), **ref)
+    print("wrote", len(names) + 1, "diag fixtures to", OUT)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "estimators":
         estimators()
+    elif len(sys.argv) > 1 and sys.argv[1] == "diag":
+        diag()
     else:
         main()
         estimators()
+        diag()

@@ -514,3 +514,56 @@ def test_fuzz_kwargs_f32_nested(pkg, methods):
                              co.rhat_nested(x, inds, kind=kind, split_chains=s), tol, what + " nested " + kind)
             assert_close(host(pkg.mcse(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)),
                          co.mcse_mean(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse")
+
+
+@pytest.mark.parametrize("name", golden_names(diag=True))
+def test_bfmi_gelmandiag_golden(pkg, name):
+    """bfmi (src/bfmi.jl:38-45) and gelmandiag (src/gelmandiag.jl:1-80) through the C-ABI against the committed
+    vectors, from device and from host memory; diag_bfmi_reference = the reference's known answers
+    (test/bfmi.jl:2-41)."""
+    g = load_golden(name)
+    if name == "diag_bfmi_reference":
+        assert abs(pkg.bfmi(g["energy_a"]) - 0.6) < 1e-12
+        assert abs(pkg.bfmi(g["energy_b"]) - 0.2406937229) < 1e-9
+        assert abs(pkg.bfmi([int(v) for v in g["energy_b"]]) - 0.2406937229) < 1e-9
+        em = np.repeat(g["energy_b"][:, None], 4, axis=1)
+        assert_close(pkg.bfmi(em), np.full(4, 0.2406937229), 1e-8, name)
+        assert_close(pkg.bfmi(em.T, dims=2), pkg.bfmi(em), 1e-15, name + " dims=2")  # test/bfmi.jl:41
+        return
+    x = load_golden(name[5:])["x"]
+    f32 = x.dtype == np.float32
+    tol = 2e-6 if f32 else RTOL64
+    for src in (dev(x), x):
+        for k, want in g.items():
+            if k.startswith("gelman|"):
+                _, alpha, which = k.split("|")
+                r = pkg.gelmandiag(src, alpha=float(alpha))
+                got = host(getattr(r, which))
+                assert got.dtype == np.float64 and got.shape == (x.shape[2],)
+                assert_close(got, want, tol, f"{name} {k}")
+        e = x.reshape(x.shape[0], -1, order="F")
+        got = host(pkg.bfmi(dev(e[:, :, None])[:, :, 0] if src is not x else e))
+        assert_close(got, g["bfmi"], 2e-5 if f32 else RTOL64, name + " bfmi")
+
+
+def test_gelmandiag_bfmi_shapes_and_errors(pkg):
+    """result types (test/gelmandiag.jl:8-16), the two-chain requirement (:29), big seeded input vs the oracle"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((100, 2, 4))
+    r = pkg.gelmandiag(x)
+    assert r._fields == ("psrf", "psrfci") and r.psrf.shape == (4,) and r.psrf.dtype == np.float64
+    with pytest.raises(pkg.ErrorException):
+        pkg.gelmandiag(x[:, :1, :])
+    x = ar1(0.6, 4000, 6, 300, rng) + rng.standard_normal((1, 6, 300)) * 0.05
+    want = co.gelmandiag(x, alpha=0.05)
+    got = pkg.gelmandiag(dev(x))
+    assert_close(host(got.psrf), want[0], RTOL64, "psrf")
+    assert_close(host(got.psrfci), want[1], RTOL64, "psrfci")
+    e = rng.standard_normal((777, 5)).cumsum(axis=0)
+    assert_close(host(pkg.bfmi(e)), co.bfmi(e), RTOL64, "bfmi")
+    one = rng.standard_normal(1)
+    assert math.isnan(pkg.bfmi(one))  # var of one draw is NaN
+    const = np.ones((50, 3, 2))
+    r = pkg.gelmandiag(const)  # W = B = 0: NaN estimates, no F quantile taken (src/gelmandiag.jl:49)
+    assert np.isnan(r.psrf).all() and np.isnan(r.psrfci).all()

@@ -119,3 +119,32 @@ def test_estimator_golden(name):
             _, est, p = k.split("|")
             assert_close(co.mcse_quantile(x, est, prob=float(p)), want, 1e-12, f"{name} {k}")
     assert n > 0
+
+
+@pytest.mark.parametrize("name", golden_names(diag=True))
+def test_diag_golden(name):
+    """bfmi (src/bfmi.jl:38-45) and gelmandiag (src/gelmandiag.jl:1-60): the C oracle reproduces the committed
+    vectors; diag_bfmi_reference holds the reference's own known answers (test/bfmi.jl:2-41)."""
+    from oracle import c_oracle as co
+    g = load_golden(name)
+    if name == "diag_bfmi_reference":
+        assert abs(co.bfmi(g["energy_a"]) - float(g["expect_a"])) < 1e-12
+        assert abs(co.bfmi(g["energy_b"]) - float(g["expect_b"])) < 1e-9
+        assert abs(co.bfmi(g["energy_b"].astype(np.int64)) - float(g["expect_b"])) < 1e-9
+        em = np.repeat(g["energy_b"][:, None], 4, axis=1)  # repeat(energy, 1, 4), test/bfmi.jl:37-40
+        assert_close(co.bfmi(em), np.full(4, float(g["expect_b"])), 1e-8, name)
+        return
+    x = load_golden(name[5:])["x"]
+    for k, want in g.items():
+        if k.startswith("gelman|"):
+            _, alpha, which = k.split("|")
+            psrf, ci = co.gelmandiag(x, alpha=float(alpha))
+            assert_close(psrf if which == "psrf" else ci, want, 1e-12, f"{name} {k}")
+    assert_close(co.bfmi(x.reshape(x.shape[0], -1, order="F")), g["bfmi"], 1e-12, name + " bfmi")
+
+
+def test_gelmandiag_oracle_errors():
+    """fewer than two chains: ErrorException (src/gelmandiag.jl:3, test/gelmandiag.jl:29)"""
+    from oracle import c_oracle as co
+    with pytest.raises(co.OracleError):
+        co.gelmandiag(np.random.default_rng(0).standard_normal((100, 1, 3)))
