@@ -96,52 +96,88 @@ __global__ void permute_dpc_kernel(const T* __restrict__ in, T* __restrict__ out
 }
 
 
-// One workgroup per column of `draws` contiguous values: mean, corrected variance (two passes, the second one
-// re-reads the column from L2) and the mean squared first difference.  mom[3 * col + {0, 1, 2}].
-// Streaming, HBM-bound: draws * sizeof(T) algorithmic bytes per column.  (src/bfmi.jl:38-45, gelmandiag.jl:10-13)
-template <typename T>
+// (count, mean, sum of squared deviations) of two disjoint groups -> of their union (Chan, Golub & LeVeque 1979):
+// as accurate as the two-pass formula, and every value is read from memory once
+__device__ inline void chan_merge(double& na, double& ma, double& Ma, double nb, double mb, double Mb) {
+    if (nb == 0.0) return;
+    const double n = na + nb, d = mb - ma;
+    ma = ma + d * (nb / n);
+    Ma = Ma + Mb + d * d * (na * nb / n);
+    na = n;
+}
+
+// One workgroup per column of `draws` contiguous values, ONE pass over HBM: every thread keeps 16 strided values
+// of a 4096-value chunk in registers (16 independent loads in flight), takes their mean and squared deviations
+// exactly as the two-pass formula would and merges that into its running (n, mean, M2); the 256 partial
+// triples are merged by a fixed tree at the end.  MSD adds sum (x[t+1] - x[t])^2: the right neighbour comes
+// from the next lane, lane 63 loads it.  Output: bfmi_out[col] = msd / var (src/bfmi.jl:39) when given, else
+// mom[3 col + {0, 1, 2}] = mean, corrected variance, mean squared difference (src/gelmandiag.jl:10-13).
+// Streaming, HBM-bound: draws * sizeof(T) algorithmic bytes per column.
+template <typename T, bool MSD>
 __global__ __launch_bounds__(256) void column_moments_kernel(const T* __restrict__ x, long long D, long long ncol,
                                                              double* __restrict__ mom, T* __restrict__ bfmi_out) {
-    __shared__ double red[3][4];
+    constexpr int IPT = 16;
+    __shared__ double red[4][4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    auto wave_sum = [](double v) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        return v;
-    };
     for (long long col = blockIdx.x; col < ncol; col += gridDim.x) {
         const T* xc = x + col * D;
-        double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-        long long d = tid;
-        for (; d + 768 < D; d += 1024) {
-            const double a0 = (double)xc[d], a1 = (double)xc[d + 256], a2 = (double)xc[d + 512], a3 = (double)xc[d + 768];
-            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        double rn = 0.0, rmean = 0.0, rm2 = 0.0, q = 0.0;
+        for (long long c0 = 0; c0 < D; c0 += 256 * IPT) {
+            double v[IPT];
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const long long i = c0 + k * 256 + tid;
+                v[k] = (double)xc[i < D ? i : D - 1];
+            }
+            double s = 0.0, cn = 0.0;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const bool ok = c0 + k * 256 + tid < D;
+                s += ok ? v[k] : 0.0;
+                cn += ok ? 1.0 : 0.0;
+            }
+            const double cm = cn > 0.0 ? s / cn : 0.0;
+            double m2 = 0.0;
+#pragma unroll
+            for (int k = 0; k < IPT; ++k) {
+                const bool ok = c0 + k * 256 + tid < D;
+                const double e = v[k] - cm;
+                m2 += ok ? e * e : 0.0;
+            }
+            chan_merge(rn, rmean, rm2, cn, cm, m2);
+            if (MSD) {
+#pragma unroll
+                for (int k = 0; k < IPT; ++k) {
+                    const long long i = c0 + k * 256 + tid;
+                    // value of lane + 1 through the cross-lane data path (DPP wave_shl:1), no index registers
+                    const long long vb = __double_as_longlong(v[k]);
+                    const int lo = __builtin_amdgcn_update_dpp(0, (int)vb, 0x130, 0xf, 0xf, false);
+                    const int hi = __builtin_amdgcn_update_dpp(0, (int)(vb >> 32), 0x130, 0xf, 0xf, false);
+                    double nb = __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+                    if (lane == 63) nb = (double)xc[i + 1 < D ? i + 1 : D - 1];
+                    const double d = nb - v[k];
+                    q += (i + 1 < D) ? d * d : 0.0;
+                }
+            }
         }
-        for (; d < D; d += 256) s0 += (double)xc[d];
-        const double ws = wave_sum((s0 + s1) + (s2 + s3));
-        if (lane == 0) red[0][w] = ws;
-        __syncthreads();
-        const double mu = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double)D;
-        double v0 = 0, v1 = 0, q0 = 0, q1 = 0;
-        d = tid;
-        for (; d + 256 < D; d += 512) {
-            const double a0 = (double)xc[d], b0 = (double)xc[d + 1], a1 = (double)xc[d + 256];
-            const double b1 = (d + 257 < D) ? (double)xc[d + 257] : a1;
-            v0 += (a0 - mu) * (a0 - mu); v1 += (a1 - mu) * (a1 - mu);
-            q0 += (b0 - a0) * (b0 - a0); q1 += (b1 - a1) * (b1 - a1);
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { // fixed merge tree over the lanes
+            const double nb = __shfl_xor(rn, o), mb = __shfl_xor(rmean, o), Mb = __shfl_xor(rm2, o);
+            // both partners must end with the same triple: merge (lower lane, upper lane) in that order
+            double na = rn, ma = rmean, Ma = rm2, n2 = nb, m2b = mb, M2b = Mb;
+            if (lane & o) { na = nb; ma = mb; Ma = Mb; n2 = rn; m2b = rmean; M2b = rm2; }
+            chan_merge(na, ma, Ma, n2, m2b, M2b);
+            rn = na; rmean = ma; rm2 = Ma;
+            if (MSD) q += __shfl_xor(q, o);
         }
-        for (; d < D; d += 256) {
-            const double a0 = (double)xc[d], b0 = (d + 1 < D) ? (double)xc[d + 1] : a0;
-            v0 += (a0 - mu) * (a0 - mu);
-            q0 += (b0 - a0) * (b0 - a0);
-        }
-        const double wv = wave_sum(v0 + v1), wq = wave_sum(q0 + q1);
-        if (lane == 0) { red[1][w] = wv; red[2][w] = wq; }
+        if (lane == 0) { red[0][w] = rn; red[1][w] = rmean; red[2][w] = rm2; red[3][w] = q; }
         __syncthreads();
         if (tid == 0) {
+            double n = red[0][0], mu = red[1][0], M2 = red[2][0];
+            for (int k = 1; k < 4; ++k) chan_merge(n, mu, M2, red[0][k], red[1][k], red[2][k]);
             const double dm1 = (double)(D - 1);
-            const double var = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / dm1;
-            const double msd = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / dm1;
+            const double var = M2 / dm1;
+            const double msd = ((red[3][0] + red[3][1]) + (red[3][2] + red[3][3])) / dm1;
             if (bfmi_out) bfmi_out[col] = (T)(msd / var); // mean(abs2, diff(energy)) / var(energy), src/bfmi.jl:39
             else { mom[3 * col] = mu; mom[3 * col + 1] = var; mom[3 * col + 2] = msd; }
         }
@@ -181,9 +217,10 @@ __host__ __device__ static double mdt_ibeta(double a, double b, double x) {
     if (x < (a + 1.0) / (a + b + 2.0)) return bt * mdt_betacf(a, b, x) / a;
     return 1.0 - bt * mdt_betacf(b, a, 1.0 - x) / b;
 }
-__host__ __device__ static double mdt_betainvcdf(double a, double b, double p) {
+__host__ __device__ static double mdt_betainvcdf(double a, double b, double p, double xstart = -1.0) {
     double lo = 0.0, hi = 1.0, x = a / (a + b);
-    { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
+    if (xstart > 0.0 && xstart < 1.0) x = xstart;
+    else { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
         const double sd = sqrt(a * b / ((a + b) * (a + b) * (a + b + 1.0)));
         const double z = (p > 0.0 && p < 1.0) ? 0.5513288954217921 * log(p / (1.0 - p)) * 1.0 : 0.0; /* sqrt(3)/pi * logit */
         const double x0 = x + z * sd;
@@ -206,8 +243,8 @@ __host__ __device__ static double mdt_betainvcdf(double a, double b, double p) {
 // entries only) and the F quantile of :50, quantile(FDist(d1, d2), q) = d2 y / (d1 (1 - y)) with
 // y = betainvcdf(d1/2, d2/2, q).  All Float64 (:41-42).  status |= 4 when FDist would reject its parameter.
 __global__ __launch_bounds__(64) void gelman_finish_kernel(const double* __restrict__ mom, long long D, long long C, long long P,
-                                                           double alpha, double* __restrict__ psrf, double* __restrict__ psrfci,
-                                                           int* __restrict__ status) {
+                                                           double alpha, double zq, double* __restrict__ psrf,
+                                                           double* __restrict__ psrfci, int* __restrict__ status) {
     const long long p = (long long)blockIdx.x * 64 + threadIdx.x;
     if (p >= P) return;
     const double niters = (double)D, nchains = (double)C;
@@ -236,7 +273,10 @@ __global__ __launch_bounds__(64) void gelman_finish_kernel(const double* __restr
     psrf[p] = sqrt(correction * (rfixed + rrandom));
     if (rrandom == rrandom) {
         if (!(W_df > 0)) { atomicOr(status, 4); psrfci[p] = __builtin_nan(""); return; }
-        const double y = mdt_betainvcdf(B_df / 2, W_df / 2, q);
+        // start: Wilson-Hilferty chi-square quantile for the numerator, F ~ chi2(d1)/d1 for large d2
+        const double t9 = 2.0 / (9.0 * B_df), wh = 1.0 - t9 + zq * sqrt(t9);
+        const double f0 = wh * wh * wh;
+        const double y = mdt_betainvcdf(B_df / 2, W_df / 2, q, f0 > 0.0 ? B_df * f0 / (W_df + B_df * f0) : -1.0);
         rrandom *= W_df * y / (B_df * (1 - y));
     }
     psrfci[p] = sqrt(correction * (rfixed + rrandom));
@@ -780,10 +820,13 @@ static int column_moments(mdt_ctx* ctx, const mdt_args* a, const void* x, long l
         ctx->mom_cap = ncol;
     }
     const unsigned grid = (unsigned)std::min<long long>(ncol, 16LL * (ctx->num_cu > 0 ? ctx->num_cu : 256));
-    if (a->dtype == MDT_F64)
-        hipLaunchKernelGGL(column_moments_kernel<double>, dim3(grid), dim3(256), 0, st, (const double*)dx, D, ncol, ctx->mom, (double*)bfmi_dev);
-    else
-        hipLaunchKernelGGL(column_moments_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dx, D, ncol, ctx->mom, (float*)bfmi_dev);
+    if (a->dtype == MDT_F64) {
+        auto k = bfmi_dev ? column_moments_kernel<double, true> : column_moments_kernel<double, false>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const double*)dx, D, ncol, ctx->mom, (double*)bfmi_dev);
+    } else {
+        auto k = bfmi_dev ? column_moments_kernel<float, true> : column_moments_kernel<float, false>;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(256), 0, st, (const float*)dx, D, ncol, ctx->mom, (float*)bfmi_dev);
+    }
     HIP_TRY(hipGetLastError());
     return MDT_OK;
 }
@@ -847,8 +890,21 @@ int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha,
     }
     HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
     if ((rc = column_moments(ctx, a, x, C * P, nullptr))) return rc;
+    double zq = 0.0; // standard normal quantile of 1 - alpha/2 (a start value only): Newton on erfc
+    {
+        const double qq = 1 - alpha / 2;
+        if (qq > 0.0 && qq < 1.0)
+            for (int it = 0; it < 60; ++it) {
+                const double f = 0.5 * erfc(-zq * 0.7071067811865476) - qq, pdf = 0.3989422804014327 * exp(-0.5 * zq * zq);
+                if (!(pdf > 1e-300)) break;
+                double step = f / pdf;
+                step = step > 1.0 ? 1.0 : (step < -1.0 ? -1.0 : step);
+                zq -= step;
+                if (fabs(step) < 1e-12) break;
+            }
+    }
     hipLaunchKernelGGL(gelman_finish_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, (const double*)ctx->mom, D, C, P, alpha,
-                       od0, od1, ctx->status);
+                       zq, od0, od1, ctx->status);
     HIP_TRY(hipGetLastError());
     if (a->location == MDT_HOST) {
         HIP_TRY(hipMemcpyAsync(psrf, od0, (size_t)P * 8, hipMemcpyDeviceToHost, st));
