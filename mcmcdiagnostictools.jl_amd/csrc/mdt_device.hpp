@@ -1466,6 +1466,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
     // key's run leaves as one contiguous stream, was measured too: 17.0 ms against 16.8 ms -- the extra LDS
     // traffic and four barriers per tile cost more than the better-formed stores save.)
     {
+        const bool want_e = !momout && !noout; // the element index is only needed to scatter scores back in time order
         if (segout && tid < NKEY) kg2[tid] = segcur2[tid] - segcur[tid]; // chain-major place = place + kg2[key]
         __syncthreads();
         constexpr int UP = 10;
@@ -1501,7 +1502,7 @@ MDT_PHASE int rank_phase_q(const KP& kp_, VG vg, long long n_, unsigned char* sm
                     xsbuf[off[u]] = xv[u];
                     ksbuf[off[u]] = (unsigned short)kv[u];
                     if (segout) locbuf[off[u] + kg2[key[u]]] = (unsigned short)(e - e0tab[kv[u] >> 9 & 63u]);
-                    else esbuf[off[u]] = e;
+                    else if (want_e) esbuf[off[u]] = e;
                 }
             }
         }
