@@ -129,9 +129,10 @@ int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_
 int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
 /* mcse(x; kind = Statistics.median) and mcse(x; kind = Base.Fix2(Statistics.quantile, p)) -- replaces
- * src/mcse.jl:66-118: ESS of the indicator proxy (pass 1), the Beta(S p + 1, S (1-p) + 1) quadrature points on
- * the host, two order statistics per parameter through a second, order-statistics-only ranking (pass 2).
- * args->kind: MDT_KIND_MEDIAN or MDT_KIND_QUANTILE (p = args->tail_prob).  Synchronous between the passes. */
+ * src/mcse.jl:66-118: ESS of the indicator proxy (pass 1), the Beta(S p + 1, S (1-p) + 1) quadrature points by one
+ * device thread per parameter, two order statistics per parameter through a second, order-statistics-only ranking
+ * (pass 2); all three on args->stream, nothing returns to the host in between.
+ * args->kind: MDT_KIND_MEDIAN or MDT_KIND_QUANTILE (p = args->tail_prob). */
 int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
 /*

@@ -282,6 +282,25 @@ __global__ __launch_bounds__(64) void gelman_finish_kernel(const double* __restr
     psrfci[p] = sqrt(correction * (rfixed + rrandom));
 }
 
+// mcse(kind = median | quantile(p)), src/mcse.jl:93-108: S -> 0-based positions of the order statistics at the two
+// quadrature points of Beta(S p + 1, S (1 - p) + 1); one thread per parameter.  NaN ESS -> sentinel positions.
+template <typename T>
+__global__ __launch_bounds__(64) void mcse_quantile_pos_kernel(const T* __restrict__ ess, long long P, double p, long long n,
+                                                               unsigned int* __restrict__ tp) {
+    const long long i = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= P) return;
+    const double S = (double)ess[i];
+    if (S != S) { tp[2 * i] = 0xFFFFFFFFu; tp[2 * i + 1] = 0xFFFFFFFFu; return; }
+    const double alpha = S * p + 1.0, beta = S * (1.0 - p) + 1.0;
+    const double pu = mdt_betainvcdf(alpha, beta, 0.8413447460685429);  // normcdf(1)
+    const double pl = mdt_betainvcdf(alpha, beta, 0.15865525393145705); // normcdf(-1)
+    long long l = (long long)floor(pl * (double)n), u = (long long)ceil(pu * (double)n);
+    if (l < 1) l = 1;
+    if (u > n) u = n;
+    tp[2 * i] = (unsigned int)(l - 1);
+    tp[2 * i + 1] = (unsigned int)(u - 1);
+}
+
 constexpr unsigned KP_RING = 64;
 
 int fail(mdt_ctx* ctx, int code, const std::string& msg) {
@@ -349,6 +368,7 @@ struct Req {
     const int32_t* chain_inds = nullptr; int K = 0, S = 0;
     const unsigned int* tpos_arr = nullptr; // mode 5
     int want_ess = 0; // ESS of some kind is requested (drives the maxlag domain check)
+    int keep_status = 0; // second pass of a two-pass request: the flags of the first pass are still to be reported
 };
 
 int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
@@ -446,7 +466,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         }
         HIP_TRY(hipMemcpyAsync(ctx->chain_inds, rq.chain_inds, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
+    // word 0: status flags, word 1: the kernel's parameter ticket
+    if (rq.keep_status) HIP_TRY(hipMemsetAsync(ctx->status + 1, 0, sizeof(int), st));
+    else HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
 
     KP kp;
     memset(&kp, 0, sizeof(kp));
@@ -721,54 +743,53 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
         HIP_TRY(hipMalloc((void**)&ctx->tpos_arr, (size_t)P * 2 * sizeof(unsigned int)));
         ctx->mq_cap = P;
     }
-    // pass 1: S = ess(x; kind = median | quantile(p))  (src/mcse.jl:73, 84)
-    std::string hostS((size_t)P * 8, '\0');
+    // pass 1: S = ess(x; kind = median | quantile(p))  (src/mcse.jl:73, 84), kept on the device
     mdt_args a1 = *a;
-    a1.sync = 1;
+    a1.location = MDT_DEVICE;
+    a1.sync = 0;
+    const void* dx = x;
+    if (a->location == MDT_HOST) { // stage x once for both passes
+        const size_t xb = (size_t)n * P * ts;
+        if (xb > ctx->stage_x_cap) {
+            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
+            ctx->stage_x_cap = xb;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
+        dx = ctx->stage_x;
+    }
     Req r1;
     r1.est = a->kind; r1.want_ess = 1;
-    r1.out_eb = (a->location == MDT_HOST) ? (void*)&hostS[0] : ctx->ess_tmp;
-    int rc = run(ctx, &a1, x, r1);
+    r1.out_eb = ctx->ess_tmp;
+    int rc = run(ctx, &a1, dx, r1);
     if (rc) return rc;
-    if (a->location == MDT_DEVICE) {
-        HIP_TRY(hipMemcpyAsync(&hostS[0], ctx->ess_tmp, (size_t)P * ts, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-    }
-    // positions of the two quadrature points of the Beta error distribution (src/mcse.jl:93-108)
-    std::string hostT((size_t)P * 2 * sizeof(unsigned int), '\0');
-    unsigned int* tp = (unsigned int*)&hostT[0];
-    {
-        const char* hs = &hostS[0];
-        const int f32 = a->dtype == MDT_F32;
-        auto work = [=](long long i0, long long i1) {
-            for (long long i = i0; i < i1; ++i) {
-                const double S = f32 ? (double)((const float*)hs)[i] : ((const double*)hs)[i];
-                if (S != S) { tp[2 * i] = 0xFFFFFFFFu; tp[2 * i + 1] = 0xFFFFFFFFu; continue; }
-                const double alpha = S * p + 1.0, beta = S * (1.0 - p) + 1.0;
-                const double pu = mdt_betainvcdf(alpha, beta, 0.8413447460685429);  // normcdf(1)
-                const double pl = mdt_betainvcdf(alpha, beta, 0.15865525393145705); // normcdf(-1)
-                long long l = (long long)floor(pl * (double)n), u = (long long)ceil(pu * (double)n);
-                if (l < 1) l = 1;
-                if (u > n) u = n;
-                tp[2 * i] = (unsigned int)(l - 1);
-                tp[2 * i + 1] = (unsigned int)(u - 1);
-            }
-        };
-        // independent per parameter: a few host threads for big batches (~30 us of scalar math each)
-        unsigned nth = std::thread::hardware_concurrency();
-        nth = nth > 16 ? 16 : (nth < 1 ? 1 : nth);
-        if (P < 512) nth = 1;
-        std::vector<std::thread> th;
-        const long long per = (P + nth - 1) / nth;
-        for (unsigned t = 1; t < nth; ++t) th.emplace_back(work, (long long)t * per, std::min(P, (long long)(t + 1) * per));
-        work(0, std::min(P, per));
-        for (auto& t : th) t.join();
-    }
-    HIP_TRY(hipMemcpyAsync(ctx->tpos_arr, tp, hostT.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st)); // (hostT goes out of scope)
+    // positions of the two quadrature points of the Beta error distribution (src/mcse.jl:93-108): one thread
+    // per parameter, same stream
+    if (a->dtype == MDT_F32)
+        hipLaunchKernelGGL(mcse_quantile_pos_kernel<float>, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, (const float*)ctx->ess_tmp, P, p, n, ctx->tpos_arr);
+    else
+        hipLaunchKernelGGL(mcse_quantile_pos_kernel<double>, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, (const double*)ctx->ess_tmp, P, p, n, ctx->tpos_arr);
+    HIP_TRY(hipGetLastError());
     // pass 2: the two order statistics, (xu - xl) / 2  (src/mcse.jl:109-117)
     Req r2;
-    r2.mode = 5; r2.out_eb = mcse_out; r2.tpos_arr = ctx->tpos_arr;
+    r2.mode = 5; r2.out_eb = mcse_out; r2.tpos_arr = ctx->tpos_arr; r2.keep_status = 1;
+    if (a->location == MDT_HOST) { // x is already staged: run on the device copy, bring the result back
+        const size_t ob = (size_t)P * ts;
+        if (ob > ctx->stage_out_cap) {
+            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+            ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->stage_out, ob));
+            ctx->stage_out_cap = ob;
+        }
+        r2.out_eb = ctx->stage_out;
+        a1.sync = 1;
+        rc = run(ctx, &a1, dx, r2);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(mcse_out, ctx->stage_out, ob, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return MDT_OK;
+    }
     return run(ctx, a, x, r2);
 }
 

@@ -567,3 +567,26 @@ def test_gelmandiag_bfmi_shapes_and_errors(pkg):
     const = np.ones((50, 3, 2))
     r = pkg.gelmandiag(const)  # W = B = 0: NaN estimates, no F quantile taken (src/gelmandiag.jl:49)
     assert np.isnan(r.psrf).all() and np.isnan(r.psrfci).all()
+
+
+def test_mcse_quantile_nan_and_async_passes(pkg):
+    """mcse(kind = quantile(p)) on data holding a NaN: Statistics.quantile throws (src/mcse.jl:84 -> ess_rhat.jl:655);
+    the flag raised by the first device pass must survive the second one.  kind = median propagates NaN instead."""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((400, 3, 6))
+    x[17, 1, 2] = np.nan
+    with pytest.raises(pkg.ArgumentError):
+        pkg.mcse(dev(x), kind=pkg.Quantile(0.3))
+    with pytest.raises(pkg.ArgumentError):
+        pkg.mcse(x, kind=pkg.Quantile(0.3))
+    got = host(pkg.mcse(dev(x), kind=np.median))
+    want = co.mcse_quantile(x, "median")
+    assert np.isnan(got[2]) and np.isnan(want[2])
+    assert_close(got, want, RTOL64, "mcse median with a NaN parameter")
+    # many parameters, device and host memory, against the oracle
+    x = ar1(0.5, 600, 4, 700, rng)
+    for kind, est, p in ((np.median, "median", 0.5), (pkg.Quantile(0.9), "quantile", 0.9)):
+        want = co.mcse_quantile(x, est, prob=p)
+        assert_close(host(pkg.mcse(dev(x), kind=kind)), want, RTOL64, f"mcse {est} device")
+        assert_close(host(pkg.mcse(x, kind=kind)), want, RTOL64, f"mcse {est} host")
