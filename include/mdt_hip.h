@@ -176,6 +176,14 @@ int mdt_rank_normalize(mdt_ctx* ctx, const mdt_args* args, const void* x, int32_
  */
 int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset);
 
+/*
+ * Diagnostics, host only (no GPU is touched): the library's regularised incomplete beta function I_v(a, b)
+ * (inverse == 0) or its inverse in v (inverse != 0) -- the code behind the quadrature points of
+ * src/mcse.jl:105-106 and the F quantile of src/gelmandiag.jl:50 (csrc/mdt_beta.hpp, compiled for host and
+ * device from one source), so that it can be checked against an independent implementation.
+ */
+int mdt_debug_beta(double a, double b, double v, int32_t inverse, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ OUT_ESS, OUT_RHAT = 1, 2
 # every symbol include/mdt_hip.h declares
 SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_destroy", "mdt_last_error", "mdt_ess_rhat",
            "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile", "mdt_rank_normalize", "mdt_layout_from_dpc",
-           "mdt_bfmi", "mdt_gelmandiag", "mdt_debug_phase_cycles")
+           "mdt_bfmi", "mdt_gelmandiag", "mdt_debug_phase_cycles", "mdt_debug_beta")
 
 
 class MdtArgs(ctypes.Structure):
@@ -86,6 +86,7 @@ def load():
         lib.mdt_gelmandiag.argtypes = [vp, ap, vp, ctypes.c_double, vp, vp]
         lib.mdt_rank_normalize.argtypes = [vp, ap, vp, i32, vp, vp]
         lib.mdt_debug_phase_cycles.argtypes = [vp, ctypes.POINTER(ctypes.c_uint64), i32]
+        lib.mdt_debug_beta.argtypes = [ctypes.c_double, ctypes.c_double, ctypes.c_double, i32, ctypes.POINTER(ctypes.c_double)]
         _ = i64
         _lib = lib
     return _lib

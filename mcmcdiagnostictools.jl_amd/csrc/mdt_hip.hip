@@ -30,6 +30,7 @@
 // passes every test; measured 23.7 ms against 18.3 ms on the headline shape: the barrier-heavy partition and
 // the register-hungry lag products lose more than the count / histogram passes gain.  Not instantiated.)
 #include "mdt_hip.h"
+#include "mdt_beta.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -183,60 +184,6 @@ __global__ __launch_bounds__(256) void column_moments_kernel(const T* __restrict
         }
         __syncthreads();
     }
-}
-
-/* Regularised incomplete beta I_x(a, b) (continued fraction, modified Lentz) and its inverse (safeguarded
- * Newton): StatsFuns.betainvcdf of src/mcse.jl:105-106.  Agrees with scipy.special.betaincinv to ~1e-11. */
-__host__ __device__ static double mdt_betacf(double a, double b, double x) {
-    const double qab = a + b, qap = a + 1.0, qam = a - 1.0, tiny = 1e-300;
-    double c = 1.0, d = 1.0 - qab * x / qap;
-    if (fabs(d) < tiny) d = tiny;
-    d = 1.0 / d;
-    double h = d;
-    for (int m = 1; m < 2000; ++m) {
-        const double m2 = 2.0 * m;
-        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
-        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d; h *= d * c;
-        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
-        d = 1.0 + aa * d; if (fabs(d) < tiny) d = tiny;
-        c = 1.0 + aa / c; if (fabs(c) < tiny) c = tiny;
-        d = 1.0 / d;
-        const double de = d * c;
-        h *= de;
-        if (fabs(de - 1.0) < 3e-16) break;
-    }
-    return h;
-}
-__host__ __device__ static double mdt_ibeta(double a, double b, double x) {
-    if (x <= 0.0) return 0.0;
-    if (x >= 1.0) return 1.0;
-    const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
-    const double bt = exp(a * log(x) + b * log1p(-x) - lb);
-    if (x < (a + 1.0) / (a + b + 2.0)) return bt * mdt_betacf(a, b, x) / a;
-    return 1.0 - bt * mdt_betacf(b, a, 1.0 - x) / b;
-}
-__host__ __device__ static double mdt_betainvcdf(double a, double b, double p, double xstart = -1.0) {
-    double lo = 0.0, hi = 1.0, x = a / (a + b);
-    if (xstart > 0.0 && xstart < 1.0) x = xstart;
-    else { /* start from the normal approximation: mean + z(p) * sd, z by a crude inverse of the logistic fit */
-        const double sd = sqrt(a * b / ((a + b) * (a + b) * (a + b + 1.0)));
-        const double z = (p > 0.0 && p < 1.0) ? 0.5513288954217921 * log(p / (1.0 - p)) * 1.0 : 0.0; /* sqrt(3)/pi * logit */
-        const double x0 = x + z * sd;
-        if (x0 > 0.0 && x0 < 1.0) x = x0;
-    }
-    const double lb = lgamma(a) + lgamma(b) - lgamma(a + b);
-    for (int it = 0; it < 200; ++it) {
-        const double f = mdt_ibeta(a, b, x) - p;
-        if (f > 0.0) hi = x; else lo = x;
-        const double pdf = (x > 0.0 && x < 1.0) ? exp((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lb) : 0.0;
-        double xn = (pdf > 0.0) ? x - f / pdf : 0.5 * (lo + hi);
-        if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-        if (fabs(xn - x) <= 4e-16 * x) { x = xn; break; } /* (two neighbouring doubles would otherwise alternate until the cap) */
-        x = xn;
-    }
-    return x;
 }
 
 // One thread per parameter: the flops that follow the per-chain moments (src/gelmandiag.jl:5-57, the diagonal
@@ -937,6 +884,12 @@ int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha,
         HIP_TRY(hipStreamSynchronize(st));
         if (status & 4) return fail(ctx, MDT_EARG, "FDist: the condition nu2 > zero(nu2) is not satisfied"); // Distributions.FDist
     }
+    return MDT_OK;
+}
+
+int mdt_debug_beta(double a, double b, double v, int32_t inverse, double* out) {
+    if (!out || !(a > 0.0) || !(b > 0.0) || !(v >= 0.0 && v <= 1.0)) return MDT_EARG;
+    *out = inverse ? mdt_betainvcdf(a, b, v) : mdt_ibeta(a, b, v);
     return MDT_OK;
 }
 

@@ -87,3 +87,25 @@ def test_shard_bounds(pkg):
         assert all(b[i][1] == b[i + 1][0] for i in range(W - 1))
         sizes = [hi - lo for lo, hi in b]
         assert max(sizes) - min(sizes) <= 1
+
+
+def test_library_beta_inverse_against_scipy(pkg):
+    """csrc/mdt_beta.hpp (one source for host and device): I_x(a, b) and its inverse -- the quadrature points of
+    src/mcse.jl:105-106 and the F quantile of src/gelmandiag.jl:50 -- against scipy.special, through the host-only
+    diagnostics entry point (no GPU is touched)."""
+    import ctypes
+    from scipy.special import betainc, betaincinv
+    lib = pkg._lib.load()
+    out = ctypes.c_double()
+    cases = [(S * p + 1, S * (1 - p) + 1) for S in (5.3, 40.0, 333.0, 2500.0, 19000.0) for p in (0.5, 0.1, 0.9, 0.01, 0.25)]
+    cases += [(d1 / 2, d2 / 2) for d1 in (1, 3, 7, 15, 63) for d2 in (2.5, 30.0, 400.0, 5000.0, 40000.0, 1e6)]
+    worst_inv = worst_fwd = 0.0
+    for a, b in cases:
+        for q in (0.15865525393145705, 0.8413447460685429, 0.975, 0.9, 0.5, 0.025):
+            assert lib.mdt_debug_beta(a, b, q, 1, ctypes.byref(out)) == 0
+            xs = betaincinv(a, b, q)
+            worst_inv = max(worst_inv, abs(out.value / xs - 1))
+            assert lib.mdt_debug_beta(a, b, xs, 0, ctypes.byref(out)) == 0
+            worst_fwd = max(worst_fwd, abs(out.value / betainc(a, b, xs) - 1))
+    assert worst_inv < 2e-10 and worst_fwd < 2e-10, (worst_inv, worst_fwd)
+    assert lib.mdt_debug_beta(-1.0, 2.0, 0.5, 1, ctypes.byref(out)) == 1  # MDT_EARG
