@@ -302,6 +302,26 @@ int ensure_ztab(mdt_ctx* ctx, long long n, int f32, hipStream_t st) {
     return MDT_OK;
 }
 
+// device staging buffers of a host-memory request, grown lazily
+int stage_x_bytes(mdt_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->stage_x_cap) {
+        if (ctx->stage_x) (void)hipFree(ctx->stage_x);
+        ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->stage_x, bytes));
+        ctx->stage_x_cap = bytes;
+    }
+    return MDT_OK;
+}
+int stage_out_bytes(mdt_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->stage_out_cap) {
+        if (ctx->stage_out) (void)hipFree(ctx->stage_out);
+        ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->stage_out, bytes));
+        ctx->stage_out_cap = bytes;
+    }
+    return MDT_OK;
+}
+
 // what a request needs, common to all entry points
 struct Req {
     int mode = 0;
@@ -370,22 +390,12 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     double* rank_host = rq.rank_out; void* z_host = rq.z_out;
     if (a->location == MDT_HOST) {
         const size_t xb = (size_t)n * P * ts;
-        if (xb > ctx->stage_x_cap) {
-            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
-            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
-            ctx->stage_x_cap = xb;
-        }
+        if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
         size_t ob = 5 * (size_t)P * ts;
         if (rq.mode == 3) ob += (size_t)n * P * (8 + ts);
-        if (ob > ctx->stage_out_cap) {
-            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
-            ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->stage_out, ob));
-            ctx->stage_out_cap = ob;
-        }
+        if (int rcs = stage_out_bytes(ctx, ob)) return rcs;
         for (int i = 0; i < 5; ++i)
             outs_dev[i] = outs_host[i] ? (void*)((char*)ctx->stage_out + (size_t)i * P * ts) : nullptr;
         if (rq.mode == 3) {
@@ -697,12 +707,7 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
     const void* dx = x;
     if (a->location == MDT_HOST) { // stage x once for both passes
         const size_t xb = (size_t)n * P * ts;
-        if (xb > ctx->stage_x_cap) {
-            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
-            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
-            ctx->stage_x_cap = xb;
-        }
+        if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
     }
@@ -723,12 +728,7 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
     r2.mode = 5; r2.out_eb = mcse_out; r2.tpos_arr = ctx->tpos_arr; r2.keep_status = 1;
     if (a->location == MDT_HOST) { // x is already staged: run on the device copy, bring the result back
         const size_t ob = (size_t)P * ts;
-        if (ob > ctx->stage_out_cap) {
-            if (ctx->stage_out) (void)hipFree(ctx->stage_out);
-            ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->stage_out, ob));
-            ctx->stage_out_cap = ob;
-        }
+        if (int rcs = stage_out_bytes(ctx, ob)) return rcs;
         r2.out_eb = ctx->stage_out;
         a1.sync = 1;
         rc = run(ctx, &a1, dx, r2);
@@ -772,12 +772,7 @@ static int column_moments(mdt_ctx* ctx, const mdt_args* a, const void* x, long l
     const void* dx = x;
     if (a->location == MDT_HOST) {
         const size_t xb = (size_t)D * ncol * ts;
-        if (xb > ctx->stage_x_cap) {
-            if (ctx->stage_x) (void)hipFree(ctx->stage_x);
-            ctx->stage_x = nullptr; ctx->stage_x_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->stage_x, xb));
-            ctx->stage_x_cap = xb;
-        }
+        if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
     }
@@ -804,17 +799,6 @@ static int diag_args_ok(mdt_ctx* ctx, const mdt_args* a) {
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
     if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
-    return MDT_OK;
-}
-
-// device staging for `bytes` of results of a host-memory request
-static int stage_out_bytes(mdt_ctx* ctx, size_t bytes) {
-    if (bytes > ctx->stage_out_cap) {
-        if (ctx->stage_out) (void)hipFree(ctx->stage_out);
-        ctx->stage_out = nullptr; ctx->stage_out_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->stage_out, bytes));
-        ctx->stage_out_cap = bytes;
-    }
     return MDT_OK;
 }
 
