@@ -93,19 +93,28 @@ def load():
 
 
 _ctxs = {}
+MAX_CTX_PER_DEVICE = 4  # every context owns ~0.5 GB of per-workgroup scratch at the config-2 slice size
 
 
-def ctx(device):
-    """one mdt_ctx per GPU per process"""
+def ctx(device, stream=None):
+    """One mdt_ctx per (GPU, stream) per process.  A context owns the scratch its kernels work in, so requests that
+    may run concurrently -- different streams -- must not share one; requests on one stream are ordered and do.
+    At most MAX_CTX_PER_DEVICE live per GPU: the least recently created one (never the default stream's) is
+    destroyed first (mdt_ctx_destroy synchronises the device)."""
     lib = load()
-    if device not in _ctxs:
+    key = (int(device), int(stream or 0))
+    if key not in _ctxs:
+        mine = [k for k in _ctxs if k[0] == key[0]]
+        if len(mine) >= MAX_CTX_PER_DEVICE:
+            victim = next(k for k in mine if k[1] != 0)
+            lib.mdt_ctx_destroy(_ctxs.pop(victim))
         h = ctypes.c_void_p()
         rc = lib.mdt_ctx_create(ctypes.byref(h), int(device))
         if rc != MDT_OK:
             raise MdtRuntimeError(f"mdt_ctx_create(device={device}) failed with status {rc} "
                                   "(no MI355X visible? there is no CPU fallback)")
-        _ctxs[device] = h
-    return _ctxs[device]
+        _ctxs[key] = h
+    return _ctxs[key]
 
 
 def check(rc, h):

@@ -176,6 +176,12 @@ def _args(pr, kind, outputs, autocov, split_chains, maxlag, relative, tail_prob,
                         1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream)
 
 
+def _ctx(pr):
+    """the context of (device, current stream): concurrent streams never share scratch"""
+    stream = torch.cuda.current_stream(pr.buf.device).cuda_stream if pr.dev else 0
+    return _lib.ctx(pr.device_index if pr.dev else 0, stream)
+
+
 def _finish(pr, out):
     """param axes, Missing and scalar conventions of the reference (src/utils.jl:197-215)"""
     if out is None:
@@ -224,7 +230,7 @@ def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_m
     ess_o = _new_out(pr) if want_ess else None
     rhat_o = _new_out(pr) if want_rhat else None
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, _lib.KIND[kind], (1 if want_ess else 0) | (2 if want_rhat else 0), autocov, split_chains,
                   maxlag, relative, tail_prob, sync)
         rc = _lib.load().mdt_ess_rhat(h, ctypes.byref(a), pr.ptr, _optr(ess_o), _optr(rhat_o))
@@ -283,7 +289,7 @@ def bulk_tail(samples, *, relative=False, autocov_method=None, split_chains=2, m
     _warn_niter(pr, split_chains)
     outs = out if out is not None else [_new_out(pr) for _ in range(4)]
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, 0, 3, autocov, split_chains, maxlag, relative, tail_prob, sync)
         rc = _lib.load().mdt_bulk_tail(h, ctypes.byref(a), pr.ptr, *[_optr(o) for o in outs])
         _lib.check(rc, h)
@@ -322,7 +328,7 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
     pr = _prepare(samples)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, _lib.KIND[kind], 2, 0, split_chains, 250, False, 0.1)
         K, S = inds.shape
         rc = _lib.load().mdt_rhat_nested(h, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(out))
@@ -347,7 +353,7 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     _warn_niter(pr, split_chains)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         lib = _lib.load()
         if est is None or est[0] == "std":
             a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
@@ -368,7 +374,7 @@ def rank_normalize(samples, *, fold=False, want_ranks=True):
     ranks = _new_out(pr, n, (torch.float64 if pr.torch else np.float64)) if want_ranks else None
     z = _new_out(pr, n)
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         rc = _lib.load().mdt_rank_normalize(h, ctypes.byref(a), pr.ptr, 1 if fold else 0, _optr(ranks), _optr(z))
         _lib.check(rc, h)
@@ -397,7 +403,8 @@ def from_mcmcchains_layout(samples):
     pr.D, pr.C, pr.P = D, C, P
     pr.f32 = samples.dtype == torch.float32
     pr.dev, pr.buf = True, out
-    h = _lib.ctx(samples.device.index or 0)
+    pr.device_index = samples.device.index or 0
+    h = _ctx(pr)
     a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
     rc = _lib.load().mdt_layout_from_dpc(h, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
     _lib.check(rc, h)
@@ -428,7 +435,7 @@ def bfmi(energy, *, dims=1):
     pr = _prepare(e2)
     out = _new_out(pr, pr.C)
     if pr.C > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         rc = _lib.load().mdt_bfmi(h, ctypes.byref(a), pr.ptr, _optr(out))
         _lib.check(rc, h)
@@ -447,7 +454,7 @@ def gelmandiag(samples, *, alpha=0.05):
     f64 = torch.float64 if pr.torch else np.float64
     psrf, ci = _new_out(pr, pr.P, f64), _new_out(pr, pr.P, f64)
     if pr.P > 0:
-        h = _lib.ctx(pr.device_index)
+        h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         rc = _lib.load().mdt_gelmandiag(h, ctypes.byref(a), pr.ptr, float(alpha), _optr(psrf), _optr(ci))
         _lib.check(rc, h)

@@ -590,3 +590,30 @@ def test_mcse_quantile_nan_and_async_passes(pkg):
         want = co.mcse_quantile(x, est, prob=p)
         assert_close(host(pkg.mcse(dev(x), kind=kind)), want, RTOL64, f"mcse {est} device")
         assert_close(host(pkg.mcse(x, kind=kind)), want, RTOL64, f"mcse {est} host")
+
+
+def test_concurrent_streams_do_not_share_scratch(pkg):
+    """requests issued on different HIP streams may overlap on the device: every (device, stream) pair owns its
+    context (scratch, ticket, status word), so the results are those of the serial calls, bit for bit"""
+    import torch
+    rng = np.random.default_rng(11)
+    xa = dev(ar1(0.7, 2000, 4, 1500, rng))
+    xb = dev(rng.standard_normal((2000, 4, 1500)))
+    ref_a = [host(t) for t in pkg.bulk_tail(xa)]
+    ref_b = [host(t) for t in pkg.bulk_tail(xb)]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            ra = pkg.bulk_tail(xa, sync=False)
+        with torch.cuda.stream(s2):
+            rb = pkg.bulk_tail(xb, sync=False)
+        outs.append((ra, rb))
+    torch.cuda.synchronize()
+    for ra, rb in outs:
+        for got, want in zip(ra, ref_a):
+            assert np.array_equal(host(got), want, equal_nan=True)
+        for got, want in zip(rb, ref_b):
+            assert np.array_equal(host(got), want, equal_nan=True)
+    assert len({k for k in pkg._lib._ctxs if k[0] == 0}) <= pkg._lib.MAX_CTX_PER_DEVICE

@@ -37,7 +37,7 @@ def main():
     pkg = g.load_package()
     x = synth(a.draws, a.chains, a.params, torch.device("cuda", 0), 1234).permute(2, 1, 0)
     pkg.bulk_tail(x)
-    lib, h = pkg._lib.load(), pkg._lib.ctx(0)
+    lib, h = pkg._lib.load(), pkg._lib.ctx(0, torch.cuda.current_stream().cuda_stream)
     buf = (ctypes.c_uint64 * 16)()
     lib.mdt_debug_phase_cycles(h, buf, 1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
