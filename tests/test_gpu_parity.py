@@ -617,3 +617,48 @@ def test_concurrent_streams_do_not_share_scratch(pkg):
         for got, want in zip(rb, ref_b):
             assert np.array_equal(host(got), want, equal_nan=True)
     assert len({k for k in pkg._lib._ctxs if k[0] == 0}) <= pkg._lib.MAX_CTX_PER_DEVICE
+
+
+def _full_size_properties(pkg, D, C, P, n_oracle, method=None):
+    """size-independent properties on a BASELINE-sized, device-generated array (bench.synth): position independence,
+    exact invariance under an exact monotone map, rank == max(bulk, tail), and the oracle on a spread sample"""
+    import torch
+    from bench import synth
+    from oracle import c_oracle as co
+    kw = {} if method is None else {"autocov_method": method}
+    okw = {} if method is None else {"autocov": "fft"}
+    x = synth(D, C, P, torch.device("cuda", 0), 4321).permute(2, 1, 0)
+    full = [host(o) for o in pkg.bulk_tail(x, **kw)]
+    assert all(f.shape == (P,) for f in full)
+    # (a) any sub-batch reproduces the bits of the full batch
+    sel = torch.arange(3, P, max(1, P // 97), device=x.device)
+    sub = [host(o) for o in pkg.bulk_tail(x[:, :, sel].permute(2, 1, 0).contiguous().permute(2, 1, 0), **kw)]
+    for f, s in zip(full, sub):
+        assert np.array_equal(f[sel.cpu().numpy()], s, equal_nan=True)
+    # (b) x -> 2x is exact and strictly increasing: ranks, folds (|2x - 2 med| = 2 |x - med|) and indicators do not move
+    x2 = x * 2.0
+    for f, s in zip(full, pkg.bulk_tail(x2, **kw)):
+        assert np.array_equal(f, host(s), equal_nan=True)
+    del x2
+    # (c) rhat(kind = rank) == max(rhat_bulk, rhat_tail), ess(kind = bulk) == the fused bulk ESS  (src/ess_rhat.jl:416-420)
+    assert np.array_equal(host(pkg.rhat(x, kind="rank")), np.maximum(full[2], full[3]))
+    assert np.array_equal(host(pkg.ess(x, kind="bulk", **kw)), full[0])
+    # (d) the oracle on a sample spread over the IID and AR(1) halves
+    pick = np.linspace(0, P - 1, n_oracle).astype(np.int64)
+    xs = x[:, :, torch.as_tensor(pick, device=x.device)].cpu().numpy()
+    for f, w in zip(full, co.bulk_tail(xs, **okw)):
+        assert_close(f[pick], w, RTOL64, f"full size {D}x{C}x{P}")
+    # (e) the IID half behaves like IID draws (test/ess_rhat.jl:233-235 asks for 10 % on the mean)
+    iid = slice(0, P // 2)
+    assert abs(np.mean(full[0][iid]) / (D * C) - 1) < 0.1 and abs(np.mean(full[2][iid]) - 1) < 0.01
+    assert np.all(np.isfinite(full[0])) and np.all(full[2] > 0.99)
+
+
+def test_full_size_config2_properties(pkg):
+    """BASELINE config 2: 10 000 draws x 4 chains x 10 000 params Float64 (3.2 GB)"""
+    _full_size_properties(pkg, 10000, 4, 10000, 48)
+
+
+def test_full_size_config3_properties(pkg, methods):
+    """BASELINE config 3: 100 000 draws x 8 chains x 1 000 params Float64 (6.4 GB), FFTAutocovMethod forced"""
+    _full_size_properties(pkg, 100000, 8, 1000, 3, methods["fft"])
