@@ -474,7 +474,10 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); beyond, the two-level
         // partitioned variant (O(n) traffic, bins re-cut per round; it falls back to the single-level
         // partitioned variant 1 on a huge point mass); MDT_RANK_VARIANT forces one (tests, A/B timing)
-        kp.rank_variant = rv ? atoi(rv) : ((small || n >= 65535) ? 2 : 0);
+        // (two 512-thread workgroups per CU: measured crossover at draws*chains ~ 12-16 K -- below it the
+        // histogram + partition passes of the two-level variant cost more than re-streaming a slice that is
+        // only one or two rounds long: 1000 x 4 x 100 000 takes 31.8 ms instead of 35.0, 200 x 4 x 500 000 132 instead of 161)
+        kp.rank_variant = rv ? atoi(rv) : (small ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
     }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
