@@ -42,6 +42,7 @@ namespace MDT_NS {
 
 constexpr int NT = MDT_NT;          // threads per workgroup
 constexpr bool SMALL = (MDT_LDS_LIMIT <= 80 * 1024); // the 80 KiB tables (two workgroups per CU)
+constexpr bool TINY = (MDT_LDS_LIMIT <= 40 * 1024);  // the 40 KiB tables (four 256-thread workgroups per CU): short slices
 constexpr int NWAVE = NT / 64;      // 16 or 8 wave64
 constexpr int K1 = NT / 4;          // coarse buckets (sample quantiles): every 4th of the NT sorted sample values
 constexpr int FINE = 32;            // bins per coarse bucket: 1 reserved (== splitter) + 31 linear
@@ -51,10 +52,10 @@ constexpr int BIN_TOPEQ = NREG + 1; // equal to the largest sample value (reserv
 constexpr int BIN_OVER = NREG + 2;  // above the largest sample value
 constexpr int BIN_NAN = NREG + 3;   // NaN: ranked last, in index order (isless / stable sortperm)
 constexpr int NBIN = NREG + 4;
-constexpr int CH = SMALL ? (MDT_NT == 512 ? 6400 : 4096) : 13760; // elements of bin-ordered data staged in LDS per round
-constexpr int GRID = SMALL ? 512 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
+constexpr int CH = TINY ? 2816 : SMALL ? (MDT_NT == 512 ? 6400 : 4096) : 13760; // elements of bin-ordered data staged in LDS per round
+constexpr int GRID = TINY ? 256 : SMALL ? 512 : 2048; // uniform cells over [min sample, max sample] that seed the splitter search
 constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
-constexpr int TL = SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
+constexpr int TL = TINY ? 2048 : SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
 constexpr int MAXLAG_CAP = SMALL ? 255 : 1000;
 constexpr int HALO = SMALL ? 296 : 1040; // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
 constexpr int MAXM = 256;           // max number of split chains chains*split_chains
@@ -90,7 +91,7 @@ constexpr int OFF_SER = OFF_PART + NWAVE * 8 * 8;         // double ser[TL+HALO]
 constexpr int LDS_SER_END = OFF_SER + (TL + HALO) * 8;
 // indicator phase view of the big region
 constexpr int OFF_BITS = OFF_BIG;                         // uint64 bits[2][BITW]  raw ballots of one chain
-constexpr int BITW = SMALL ? 1024 : 2048;                 // => draws <= 65536 / 131072
+constexpr int BITW = TINY ? 512 : SMALL ? 1024 : 2048;    // => draws <= 32768 / 65536 / 131072
 constexpr int OFF_SBITS = OFF_BITS + 2 * BITW * 8;        // uint64 sbits[2][BITW] split-aligned words
 constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
 constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})

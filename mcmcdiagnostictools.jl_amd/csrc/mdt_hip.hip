@@ -26,7 +26,16 @@
 #undef MDT_NT
 #undef MDT_LDS_LIMIT
 #undef MDT_WAVES_PER_EU
-// (a third geometry -- 1024 threads, 80 KiB, 8 waves/SIMD at 64 VGPRs -- compiles from the same header and
+#define MDT_NS mdt_tiny
+#define MDT_NT 256
+#define MDT_LDS_LIMIT (40 * 1024)
+#define MDT_WAVES_PER_EU 4
+#include "mdt_device.hpp"
+#undef MDT_NS
+#undef MDT_NT
+#undef MDT_LDS_LIMIT
+#undef MDT_WAVES_PER_EU
+// (a fourth geometry -- 1024 threads, 80 KiB, 8 waves/SIMD at 64 VGPRs -- compiles from the same header and
 // passes every test; measured 23.7 ms against 18.3 ms on the headline shape: the barrier-heavy partition and
 // the register-hungry lag products lose more than the count / histogram passes gain.  Not instantiated.)
 #include "mdt_hip.h"
@@ -48,8 +57,8 @@ using mdtc::KP;
 struct mdt_ctx {
     int device = 0;
     int num_cu = 0;
-    int grid = 0;      // workgroups the scratch is sized for: 2 per CU (the small geometry)
-    int force_cfg = 0; // MDT_CONFIG=big|small (tests, A/B timing): 1 big, 2 small, 0 automatic
+    int grid = 0;      // workgroups of the small geometry: 2 per CU (big: 1 per CU, tiny: 4 per CU)
+    int force_cfg = 0; // MDT_CONFIG=big|small|tiny (tests, A/B timing): 1 big, 2 small, 3 tiny, 0 automatic
     std::string err;
     // per-workgroup scratch
     unsigned int* r2buf = nullptr;
@@ -58,6 +67,7 @@ struct mdt_ctx {
     unsigned short* bsbuf = nullptr;
     unsigned short* binbuf = nullptr;
     long long n_pad = 0;
+    long long scratch_elems = 0; // capacity of each scratch array, in elements (workgroups x padded slice)
     // normal-score table
     double* ztab = nullptr;
     long long ztab_n = -1;
@@ -65,7 +75,7 @@ struct mdt_ctx {
     long long ztab_cap = 0;
     // status word + nested chain indices
     int* status = nullptr;
-    unsigned long long* prof = nullptr; // [grid*16] phase cycle counters when MDT_PROF is set
+    unsigned long long* prof = nullptr; // [2*grid*16] phase cycle counters when MDT_PROF is set
     KP* kp_ring = nullptr;              // device copies of the kernel parameters, one slot per launch
     unsigned kp_next = 0;
     int* chain_inds = nullptr;
@@ -265,22 +275,24 @@ int fail(mdt_ctx* ctx, int code, const std::string& msg) {
 
 size_t tsize(int dtype) { return dtype == MDT_F32 ? 4 : 8; }
 
-int ensure_scratch(mdt_ctx* ctx, long long n) {
+int ensure_scratch(mdt_ctx* ctx, long long n, long long wgs) {
     const long long n_pad = ((n + 63) / 64) * 64;
-    if (n_pad > ctx->n_pad) {
+    const long long need = wgs * n_pad;
+    if (need > ctx->scratch_elems) {
         if (ctx->r2buf) (void)hipFree(ctx->r2buf);
         if (ctx->binbuf) (void)hipFree(ctx->binbuf);
         if (ctx->zbuf) (void)hipFree(ctx->zbuf);
         if (ctx->xsbuf) (void)hipFree(ctx->xsbuf);
         if (ctx->bsbuf) (void)hipFree(ctx->bsbuf);
-        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->xsbuf = nullptr; ctx->bsbuf = nullptr; ctx->n_pad = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)ctx->grid * n_pad * sizeof(unsigned int)));
-        HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
-        HIP_TRY(hipMalloc((void**)&ctx->zbuf, (size_t)ctx->grid * n_pad * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&ctx->xsbuf, (size_t)ctx->grid * n_pad * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&ctx->bsbuf, (size_t)ctx->grid * n_pad * sizeof(unsigned short)));
-        ctx->n_pad = n_pad;
+        ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->xsbuf = nullptr; ctx->bsbuf = nullptr; ctx->scratch_elems = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)need * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)need * sizeof(unsigned short)));
+        HIP_TRY(hipMalloc((void**)&ctx->zbuf, (size_t)need * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->xsbuf, (size_t)need * sizeof(double)));
+        HIP_TRY(hipMalloc((void**)&ctx->bsbuf, (size_t)need * sizeof(unsigned short)));
+        ctx->scratch_elems = need;
     }
+    ctx->n_pad = n_pad; // the stride of this request: every workgroup owns [blockIdx * n_pad, +n_pad)
     return MDT_OK;
 }
 
@@ -363,7 +375,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (rq.est == MDT_KIND_QUANTILE && !(a->tail_prob >= 0.0 && a->tail_prob <= 1.0))
         return fail(ctx, MDT_EARG, "quantile probability must be in [0, 1]"); // Statistics.quantile
     // engine limits
-    static_assert(mdt_big::MAXM == mdt_small::MAXM, "one limit for both geometries");
+    static_assert(mdt_big::MAXM == mdt_small::MAXM && mdt_big::MAXM == mdt_tiny::MAXM, "one limit for all geometries");
     if (m > mdt_big::MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
@@ -376,7 +388,17 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool fft_lds = fft && getenv("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
                             D <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
-    const bool small = ctx->force_cfg == 1 ? false : small_fits; // 80 KiB tables, two workgroups per CU
+    // short slices: four 256-thread workgroups per CU (40 KiB of LDS each) -- a parameter of a few thousand values
+    // is mostly barrier and latency chains, which twice as many resident workgroups hide twice as well
+    int force_cfg = ctx->force_cfg; // MDT_CONFIG is honoured per request (tests switch it between calls)
+    if (const char* c = getenv("MDT_CONFIG")) force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
+    else force_cfg = 0;
+    // (measured: 1000 x 4 x 100 000 19.5 ms against 31.8 with two 512-thread workgroups per CU, 200 x 4 x 500 000 57 against
+    // 132; the gain is gone at draws*chains = 12 000, where the chains no longer fit the z-series buffer)
+    const bool tiny_fits = small_fits && n <= 8192 && D <= (long long)mdt_tiny::BITW * 64 &&
+                           (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
+    const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
+    const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)a->stream;
@@ -406,7 +428,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         }
     }
 
-    int rc = ensure_scratch(ctx, n);
+    const long long wgs = tiny ? 2LL * ctx->grid : (small ? ctx->grid : ctx->grid / 2);
+    int rc = ensure_scratch(ctx, n, wgs);
     if (rc) return rc;
     const bool need_rank = !rq.basic || rq.mode == 3;
     if (need_rank) {
@@ -477,7 +500,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // (two 512-thread workgroups per CU: measured crossover at draws*chains ~ 12-16 K -- below it the
         // histogram + partition passes of the two-level variant cost more than re-streaming a slice that is
         // only one or two rounds long: 1000 x 4 x 100 000 takes 31.8 ms instead of 35.0, 200 x 4 x 500 000 132 instead of 161)
-        kp.rank_variant = rv ? atoi(rv) : (small ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
+        kp.rank_variant = rv ? atoi(rv) : ((small || tiny) ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
     }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
@@ -487,17 +510,18 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.status = ctx->status;
     kp.prof = ctx->prof;
 
-    const long long wgs = small ? ctx->grid : ctx->grid / 2;
     const unsigned grid = (unsigned)((P < wgs) ? P : wgs);
-    void (*kern)(const KP*) = small ? (f32 ? mdt_small::mdt_kernel<float> : mdt_small::mdt_kernel<double>)
-                                    : (f32 ? mdt_big::mdt_kernel<float> : mdt_big::mdt_kernel<double>);
+    void (*kern)(const KP*) = tiny ? (f32 ? mdt_tiny::mdt_kernel<float> : mdt_tiny::mdt_kernel<double>)
+                              : small ? (f32 ? mdt_small::mdt_kernel<float> : mdt_small::mdt_kernel<double>)
+                                      : (f32 ? mdt_big::mdt_kernel<float> : mdt_big::mdt_kernel<double>);
+    const int nthreads = tiny ? mdt_tiny::NT : (small ? mdt_small::NT : mdt_big::NT);
+    const int ldsb = tiny ? mdt_tiny::LDS_BYTES : (small ? mdt_small::LDS_BYTES : mdt_big::LDS_BYTES);
     // the parameter block travels through a small ring in device memory: the kernel reads it with
     // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
     KP* slot = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
     if (ctx->kp_next % KP_RING == 0) HIP_TRY(hipStreamSynchronize(st)); // never overwrite a slot still in flight
     HIP_TRY(hipMemcpyAsync(slot, &kp, sizeof(KP), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(small ? mdt_small::NT : mdt_big::NT), small ? mdt_small::LDS_BYTES : mdt_big::LDS_BYTES, st,
-                       (const KP*)slot);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
     HIP_TRY(hipGetLastError());
 
     if (a->location == MDT_HOST) {
@@ -539,14 +563,16 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     ctx->num_cu = prop.multiProcessorCount;
     ctx->grid = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256); // two 512-thread or one 1024-thread workgroup per CU (LDS-bound)
     if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = 2 * v; } // diagnostics: workgroups of the big geometry
-    if (const char* c = getenv("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : 0);
+    if (const char* c = getenv("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
     if (hipMalloc((void**)&ctx->status, 2 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
     // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
     const void* kerns[] = {(const void*)mdt_big::mdt_kernel<double>, (const void*)mdt_big::mdt_kernel<float>,
-                           (const void*)mdt_small::mdt_kernel<double>, (const void*)mdt_small::mdt_kernel<float>};
-    for (int ki = 0; ki < 4; ++ki) {
+                           (const void*)mdt_small::mdt_kernel<double>, (const void*)mdt_small::mdt_kernel<float>,
+                           (const void*)mdt_tiny::mdt_kernel<double>, (const void*)mdt_tiny::mdt_kernel<float>};
+    const int klds[] = {mdt_big::LDS_BYTES, mdt_big::LDS_BYTES, mdt_small::LDS_BYTES, mdt_small::LDS_BYTES, mdt_tiny::LDS_BYTES, mdt_tiny::LDS_BYTES};
+    for (int ki = 0; ki < 6; ++ki) {
         const void* k = kerns[ki];
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, ki < 2 ? mdt_big::LDS_BYTES : mdt_small::LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, klds[ki]) != hipSuccess) {
             (void)hipFree(ctx->status);
             delete ctx;
             return MDT_ERUNTIME;
@@ -558,8 +584,8 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
         return MDT_ENOMEM;
     }
     if (getenv("MDT_PROF")) {
-        if (hipMalloc((void**)&ctx->prof, (size_t)ctx->grid * 16 * sizeof(unsigned long long)) != hipSuccess ||
-            hipMemset(ctx->prof, 0, (size_t)ctx->grid * 16 * sizeof(unsigned long long)) != hipSuccess) {
+        if (hipMalloc((void**)&ctx->prof, (size_t)ctx->grid * 2 * 16 * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(ctx->prof, 0, (size_t)ctx->grid * 2 * 16 * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipFree(ctx->status);
             delete ctx;
             return MDT_ENOMEM;
@@ -886,7 +912,7 @@ int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset) {
     if (!ctx->prof) return fail(ctx, MDT_EUNSUPPORTED, "phase counters are off (create the context with MDT_PROF=1 in the environment)");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
-    const size_t cnt = (size_t)ctx->grid * 16;
+    const size_t cnt = (size_t)ctx->grid * 2 * 16; // (the tiny geometry runs 2 * grid workgroups)
     unsigned long long* h = (unsigned long long*)malloc(cnt * sizeof(unsigned long long));
     if (!h) return MDT_ENOMEM;
     hipError_t e = hipMemcpy(h, ctx->prof, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);

@@ -662,3 +662,33 @@ def test_full_size_config2_properties(pkg):
 def test_full_size_config3_properties(pkg, methods):
     """BASELINE config 3: 100 000 draws x 8 chains x 1 000 params Float64 (6.4 GB), FFTAutocovMethod forced"""
     _full_size_properties(pkg, 100000, 8, 1000, 3, methods["fft"])
+
+
+@pytest.mark.parametrize("cfg", ["tiny", "small", "big"])
+def test_every_geometry_on_the_golden_vectors(pkg, methods, monkeypatch, cfg):
+    """the three workgroup geometries (256 / 512 / 1024 threads; 40 / 80 / 160 KiB of LDS) are compiled from one
+    source and chosen by slice size; forced here (MDT_CONFIG is read per request), each reproduces the golden
+    vectors, and R-hat -- fixed-point moments -- is bit-identical across them"""
+    import warnings
+    monkeypatch.setenv("MDT_CONFIG", cfg)
+    rhats = {}
+    for name in ("cfg1_randn_1000x4x10", "ar1_500x4x10", "ties_200x4x6", "odd_1001x3x3", "special_50x2x3"):
+        g = load_golden(name)
+        xd = dev(g["x"])
+        for ke, kr, kind, method, s, ml in _keys(g):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                r = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[method], split_chains=s, maxlag=ml)
+            assert_close(host(r.ess), g[ke], RTOL64, f"{cfg} {name} {ke}")
+            assert_close(host(r.rhat), g[kr], RTOL64, f"{cfg} {name} {kr}")
+            rhats[(name, kr)] = host(r.rhat)
+    monkeypatch.delenv("MDT_CONFIG")
+    for (name, kr), want in rhats.items():
+        _, kind, method, s, ml = kr.split("|")
+        if kind in ("basic", "tail") or method != "direct" or int(ml) != 250:
+            continue  # (raw-draw moments are plain double sums; one method and maxlag is enough)
+        g = load_golden(name)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = host(pkg.rhat(dev(g["x"]), kind=kind, split_chains=int(s)))
+        assert np.array_equal(got, want, equal_nan=True), (cfg, name, kr)
