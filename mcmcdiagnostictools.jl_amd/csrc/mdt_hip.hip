@@ -394,8 +394,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (const char* c = getenv("MDT_CONFIG")) force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
     else force_cfg = 0;
     // (measured: 1000 x 4 x 100 000 19.5 ms against 31.8 with two 512-thread workgroups per CU, 200 x 4 x 500 000 57 against
-    // 132; the gain is gone at draws*chains = 12 000, where the chains no longer fit the z-series buffer)
-    const bool tiny_fits = small_fits && n <= 8192 && D <= (long long)mdt_tiny::BITW * 64 &&
+    // 132, 1000 x 12 x 30 000 28.4 against 36.1; no gain once a split chain no longer fits the z-series buffer)
+    const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 40 <= mdt_tiny::SZ && D <= (long long)mdt_tiny::BITW * 64 &&
                            (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
     const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
