@@ -258,6 +258,18 @@ __global__ __launch_bounds__(64) void mcse_quantile_pos_kernel(const T* __restri
     tp[2 * i + 1] = (unsigned int)(u - 1);
 }
 
+// Launch prologue on the compute queue: the parameter block arrives as a kernel argument and is stored into its
+// ring slot, the ticket (and, unless a first pass left flags to report, the status word) is cleared.  One small
+// kernel instead of a memset and a host-to-device copy: no hand-over between the copy engine and the compute
+// queue in front of every launch.
+__global__ void kp_setup_kernel(KP* slot, KP v, int* status, int keep_status) {
+    if (threadIdx.x == 0) {
+        *slot = v;
+        if (!keep_status) status[0] = 0;
+        status[1] = 0;
+    }
+}
+
 constexpr unsigned KP_RING = 64;
 
 int fail(mdt_ctx* ctx, int code, const std::string& msg) {
@@ -446,9 +458,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         }
         HIP_TRY(hipMemcpyAsync(ctx->chain_inds, rq.chain_inds, (size_t)cnt * sizeof(int), hipMemcpyHostToDevice, st));
     }
-    // word 0: status flags, word 1: the kernel's parameter ticket
-    if (rq.keep_status) HIP_TRY(hipMemsetAsync(ctx->status + 1, 0, sizeof(int), st));
-    else HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
+    // (status word 0: flags, word 1: the kernel's parameter ticket -- both cleared by kp_setup_kernel below)
 
     KP kp;
     memset(&kp, 0, sizeof(kp));
@@ -518,9 +528,10 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const int ldsb = tiny ? mdt_tiny::LDS_BYTES : (small ? mdt_small::LDS_BYTES : mdt_big::LDS_BYTES);
     // the parameter block travels through a small ring in device memory: the kernel reads it with
     // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
-    KP* slot = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
+    const unsigned si = ctx->kp_next++ % KP_RING;
+    KP* slot = ctx->kp_ring + si;
     if (ctx->kp_next % KP_RING == 0) HIP_TRY(hipStreamSynchronize(st)); // never overwrite a slot still in flight
-    HIP_TRY(hipMemcpyAsync(slot, &kp, sizeof(KP), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
     HIP_TRY(hipGetLastError());
 
