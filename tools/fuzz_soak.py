@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Soak test (needs a GPU; not part of the pytest suite): random shapes up to ~150 000 values per slice, splits,
+kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed]"""
+import os, sys, time, warnings
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import __graft_entry__ as g
+from conftest import ar1, assert_close
+from oracle import c_oracle as co
+
+pkg = g.load_package()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+methods = {"direct": pkg.AutocovMethod(), "fft": pkg.FFTAutocovMethod(), "bda": pkg.BDAAutocovMethod()}
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(np.transpose(x, (2, 1, 0)))).cuda().permute(2, 1, 0)
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+t0, it, worst = time.time(), 0, 0.0
+while time.time() - t0 < budget:
+    it += 1
+    big = rng.random() < 0.35
+    D = int(rng.integers(2000, 40000)) if big else int(rng.integers(5, 3000))
+    C = int(rng.integers(1, 9))
+    if D * C > 150000:
+        C = max(1, 150000 // D)
+    P = int(rng.integers(1, 4))
+    s = int(rng.integers(1, 4))
+    fl = ("normal", "ar", "ties", "skew", "offset", "mass")[it % 6]
+    if fl == "normal":
+        x = rng.standard_normal((D, C, P))
+    elif fl == "ar":
+        x = ar1(float(rng.uniform(-0.9, 0.97)), D, C, P, rng)
+    elif fl == "ties":
+        x = rng.integers(0, int(rng.integers(2, 60)), size=(D, C, P)).astype(np.float64)
+    elif fl == "skew":
+        x = np.exp(3.0 * rng.standard_normal((D, C, P)))
+    elif fl == "offset":
+        x = rng.standard_normal((D, C, P)) + 3.0 * rng.standard_normal((1, C, 1)) + 1e6
+    else:  # a point mass holding a large part of the slice
+        x = rng.standard_normal((D, C, P))
+        x[rng.random((D, C, P)) < rng.uniform(0.05, 0.7)] = 0.25
+    ml = int(rng.choice([1, 7, 100, 250]))
+    m = ("direct", "fft", "bda")[it % 3]
+    cfg = ("", "", "small", "big", "tiny")[it % 5]
+    if cfg:
+        os.environ["MDT_CONFIG"] = cfg
+    else:
+        os.environ.pop("MDT_CONFIG", None)
+    xd = dev(x)
+    what = f"it={it} {fl} D={D} C={C} P={P} s={s} ml={ml} {m} cfg={cfg or 'auto'}"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kind in ("rank", "bulk", "tail", "basic"):
+            S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
+            We, Wr = co.ess_rhat(x, kind=kind, autocov=m, split_chains=s, maxlag=ml)
+            assert_close(host(S), We, 1e-8, what + f" ess {kind}")
+            assert_close(host(R), Wr, 1e-8, what + f" rhat {kind}")
+        eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
+        wb = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml)
+        for a, b in zip((eb, et, rb, rt), wb):
+            assert_close(host(a), b, 1e-8, what + " fused")
+        for est, kind in (("median", np.median), ("mad", "mad")):
+            got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
+            assert_close(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), 1e-8, what + " " + est)
+        if C * s >= 2 and C % 2 == 0 and C >= 4:
+            ids = np.repeat(np.arange(C // 2), 2)
+            got = pkg.rhat_nested(xd, ids, kind="rank", split_chains=s)
+            K, S2 = 2, C // 2
+            inds = np.arange(C, dtype=np.int32).reshape(S2, K).T.copy()
+            assert_close(host(got), co.rhat_nested(x, inds, kind="rank", split_chains=s), 1e-8, what + " nested")
+print(f"fuzz soak: {it} random requests x 8-9 calls each agreed with the oracle in {time.time() - t0:.0f} s")
