@@ -48,6 +48,10 @@ while time.time() - t0 < budget:
     else:  # a point mass holding a large part of the slice
         x = rng.standard_normal((D, C, P))
         x[rng.random((D, C, P)) < rng.uniform(0.05, 0.7)] = 0.25
+    f32 = it % 4 == 3 and fl != "offset"  # (1e6 offsets leave Float32 with ~4 digits of the signal)
+    if f32:
+        x = x.astype(np.float32)
+    tol = 5e-6 if f32 else 1e-8
     ml = int(rng.choice([1, 7, 100, 250]))
     m = ("direct", "fft", "bda")[it % 3]
     cfg = ("", "", "small", "big", "tiny")[it % 5]
@@ -56,25 +60,25 @@ while time.time() - t0 < budget:
     else:
         os.environ.pop("MDT_CONFIG", None)
     xd = dev(x)
-    what = f"it={it} {fl} D={D} C={C} P={P} s={s} ml={ml} {m} cfg={cfg or 'auto'}"
+    what = f"it={it} {fl} {x.dtype} D={D} C={C} P={P} s={s} ml={ml} {m} cfg={cfg or 'auto'}"
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for kind in ("rank", "bulk", "tail", "basic"):
             S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             We, Wr = co.ess_rhat(x, kind=kind, autocov=m, split_chains=s, maxlag=ml)
-            assert_close(host(S), We, 1e-8, what + f" ess {kind}")
-            assert_close(host(R), Wr, 1e-8, what + f" rhat {kind}")
+            assert_close(host(S), We, tol, what + f" ess {kind}")
+            assert_close(host(R), Wr, tol, what + f" rhat {kind}")
         eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
         wb = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml)
         for a, b in zip((eb, et, rb, rt), wb):
-            assert_close(host(a), b, 1e-8, what + " fused")
+            assert_close(host(a), b, tol, what + " fused")
         for est, kind in (("median", np.median), ("mad", "mad")):
             got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
-            assert_close(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), 1e-8, what + " " + est)
+            assert_close(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), tol, what + " " + est)
         if C * s >= 2 and C % 2 == 0 and C >= 4:
             ids = np.repeat(np.arange(C // 2), 2)
             got = pkg.rhat_nested(xd, ids, kind="rank", split_chains=s)
             K, S2 = 2, C // 2
             inds = np.arange(C, dtype=np.int32).reshape(S2, K).T.copy()
-            assert_close(host(got), co.rhat_nested(x, inds, kind="rank", split_chains=s), 1e-8, what + " nested")
+            assert_close(host(got), co.rhat_nested(x, inds, kind="rank", split_chains=s), tol, what + " nested")
 print(f"fuzz soak: {it} random requests x 8-9 calls each agreed with the oracle in {time.time() - t0:.0f} s")
