@@ -121,6 +121,7 @@ struct KP {
     const unsigned int* tpos_arr; // mode 5: [P][2] zero-based sorted positions (l-1, u-1) per parameter; 0xFFFFFFFF: NaN
     int fft_lds;                // FFTAutocovMethod: 1 = run the in-LDS transform when it fits (MDT_FFT_LDS=1), 0 = lagged products
     int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
+    int fold_merge;             // 1: rank |x - median| by merging the sorted slice when the ranking of x left one (fold_merge_phase); 0: always the general ranking (MDT_FOLD_MERGE=0: tests, A/B timing)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
@@ -407,6 +408,8 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
 
 #include "mdt_rank.inc"
 
+#include "mdt_fold.inc"
+
 #include "mdt_series.inc"
 
 #include "mdt_indicator.inc"
@@ -629,12 +632,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                                   // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
                                   (est_ind || kp.mode == 5 || (!(kp.need_eb || kp.need_rb) && kp.mode != 3)) ? 4
                                       // nested R-hat only needs the moments (and has no ess_rhat twin whose bits it must match)
-                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : 0)));
+                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : 0)),
+                                  // the folded ranking that follows is a merge of the sorted slice (fold_merge_phase)
+                                  kp.need_rt && kp.mode != 3 && kp.fold_merge);
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
         }
+        // the ranking left the slice sorted, tags in sorted order, no ties, no NaN (rank_phase_q, srt)
+        const bool sorted_ok = need_rank_x && kp.rank_variant == 2 && rk != 0 && uni(((int*)(smem + OFF_INTS))[18]) != 0;
         MDT_PROF_MARK(PH_RANKX);
         if (kp.mode == 5) { // _mcse_quantile (src/mcse.jl:109-117): half the distance of two order statistics, in T
             if (tid == 0) store_out<T>(kp.out_eb, p, (double)(T)(((T)ostat[1] - (T)ostat[0]) / (T)2));
@@ -746,7 +753,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
-            rank_folded(0, kp.mode != 3 ? 2 : 0);
+            rk = 0;
+            if (sorted_ok && (medT - medT == (T)0)) rk = fold_merge_phase<T>(kp, medT, n, smem, xs, bs);
+            if (rk != 3) rank_folded(0, kp.mode != 3 ? 2 : 0);
             MDT_PROF_MARK(PH_RANKF);
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
             // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores

@@ -512,6 +512,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // only one or two rounds long: 1000 x 4 x 100 000 takes 31.8 ms instead of 35.0, 200 x 4 x 500 000 132 instead of 161)
         kp.rank_variant = rv ? atoi(rv) : ((small || tiny) ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
     }
+    { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
