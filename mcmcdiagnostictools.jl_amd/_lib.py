@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmdt_hip.so")
+# MDT_LIB: another build of the same library (A/B timing, diagnostics builds); never a different implementation
+LIB_PATH = os.environ.get("MDT_LIB") or os.path.join(_HERE, "csrc", "libmdt_hip.so")
 
 MDT_OK, MDT_EARG, MDT_EDOMAIN, MDT_EDIM, MDT_ERUNTIME, MDT_ENOMEM, MDT_EUNSUPPORTED = range(7)
 MDT_F64, MDT_F32 = 0, 1

@@ -153,13 +153,20 @@ using mdtc::KP;
 // phase slots of KP::prof
 enum { PH_LOAD = 0, PH_RANKX = 1, PH_SERB = 2, PH_RANKF = 3, PH_SERT = 4, PH_IND = 5, PH_OUT = 6,
        PH_R_SAMPLE = 8, PH_R_HIST = 9, PH_R_SCAN = 10, PH_R_PLACE = 11, PH_R_COUNT = 12 };
-#ifdef MDT_PROF_Q /* diagnostics build: the z-series sub-slots are lent to the two-level rank phase */
+#if defined(MDT_PROF_F) /* diagnostics build: the z-series sub-slots are lent to fold_merge_phase */
+#define MDT_PROF_QMARK(slot)
+#define MDT_PROF_ZMARK(slot)
+#define MDT_PROF_FMARK(slot) MDT_PROF_MARK(slot)
+#define MDT_PROF_QSEL(a, b) (a)
+#elif defined(MDT_PROF_Q) /* diagnostics build: the z-series sub-slots are lent to the two-level rank phase */
 #define MDT_PROF_QMARK(slot) MDT_PROF_MARK(slot)
 #define MDT_PROF_ZMARK(slot)
+#define MDT_PROF_FMARK(slot)
 #define MDT_PROF_QSEL(a, b) (b)
 #else
 #define MDT_PROF_QMARK(slot)
 #define MDT_PROF_ZMARK(slot) MDT_PROF_MARK(slot)
+#define MDT_PROF_FMARK(slot)
 #define MDT_PROF_QSEL(a, b) (a)
 #endif
 #define MDT_PROF_MARK(slot)                                                                   \
@@ -248,6 +255,17 @@ struct SerZ {          // series = normal scores, already in time order in the p
     __device__ __forceinline__ double operator()(int c, long long row) const { return z[(long long)c * D + row]; }
 };
 #define MDT_PHASE __device__ __attribute__((noinline))
+// The dynamic LDS block reaches the phase functions as a plain pointer, but the compiler knows which symbol it is and
+// re-derives its address wherever it is used -- in a function that is not a kernel that is a LOAD from a table in
+// global memory (llvm.amdgcn.dynlds.offset.table), rematerialised inside hot loops (17 exposed L2 round trips in
+// series_z_phase).  Pinning the LDS address once per phase in a scalar register makes every later access base + offset.
+#define MDT_LA __attribute__((address_space(3)))
+__device__ __forceinline__ unsigned char* lds_pin(unsigned char* p) {
+    unsigned a = (unsigned)(unsigned long long)(MDT_LA unsigned char*)p;
+    a = (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    asm volatile("" : "+s"(a));
+    return (unsigned char*)(MDT_LA unsigned char*)(unsigned long long)a;
+}
 // Keeps a loaded value "used" so that the compiler cannot sink the load under the condition of a later
 // select (it then branches around every single LDS read and waits for each one separately).  Call it in a
 // SECOND loop, after all the loads of a batch were issued: the value must be in its register at the asm.

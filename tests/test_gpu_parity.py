@@ -692,3 +692,57 @@ def test_every_geometry_on_the_golden_vectors(pkg, methods, monkeypatch, cfg):
             warnings.simplefilter("ignore")
             got = host(pkg.rhat(dev(g["x"]), kind=kind, split_chains=int(s)))
         assert np.array_equal(got, want, equal_nan=True), (cfg, name, kr)
+
+
+def _fold_cases(rng, D, C):
+    """parameters that exercise every branch of fold_merge_phase: no ties, folds tied across the median (x distinct),
+    folds rounded together, ties in x (general ranking), one -Inf / +Inf, AR(1)"""
+    n = D * C
+    cols = [rng.standard_normal(n), ar1(0.8, D, C, 1, rng)[:, :, 0].T.reshape(-1)]
+    d = np.abs(rng.standard_normal(n // 2)) + 1e-3
+    cols.append(rng.permutation(np.concatenate([d, -d] + ([np.zeros(1)] if n % 2 else []))))  # median exactly 0: every fold is a tied pair
+    part = rng.standard_normal(n)
+    k = n // 10
+    part[:k] = 2.0 + np.abs(part[:k])
+    part[k:2 * k] = -part[:k]
+    part[2 * k:] = part[2 * k:] - np.median(part[2 * k:])                       # a tenth of the folds tied in pairs ...
+    cols.append(rng.permutation(part))
+    cols.append(rng.permutation(np.concatenate([1e-17 * np.arange(1, n // 2 + 1), 1.0 + np.abs(rng.standard_normal(n - n // 2))])))
+    few = rng.uniform(0.25, 0.75, n)
+    few[:30] = 1e-17 * np.arange(1, 31)                                         # ... and a few rounded together (the exact pass)
+    cols.append(rng.permutation(few))
+    cols.append(np.round(rng.standard_normal(n) * 4) / 4)                       # ties in x itself
+    inf = rng.standard_normal(n)
+    inf[17] = np.inf
+    inf[n - 5] = -np.inf
+    cols.append(inf)
+    odd = rng.standard_normal(n)
+    cols.append(odd)
+    return np.stack([c.reshape(C, D).T for c in cols], axis=2)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fold_merge_matches_general_ranking(pkg, monkeypatch, dtype):
+    """rhat(kind = tail) from the merge of the sorted slice (fold_merge_phase) == from the general ranking of
+    |x - median|, bit for bit (exact fixed-point moments), and both match the oracle"""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(2024)
+    for D, C in ((5000, 4), (4001, 5)):
+        x = _fold_cases(rng, D, C).astype(dtype)
+        xd = dev(x)
+        outs = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("MDT_FOLD_MERGE", sw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                outs[sw] = [host(o) for o in pkg.bulk_tail(xd)] + [host(pkg.rhat(xd, kind="rank"))]
+                ids = np.repeat(np.arange(1, 3), C // 2) if C % 2 == 0 else None
+                if ids is not None:
+                    outs[sw].append(host(pkg.rhat_nested(xd, ids, kind="rank")))
+        monkeypatch.delenv("MDT_FOLD_MERGE")
+        for a, b in zip(outs["1"], outs["0"]):
+            assert np.array_equal(a, b, equal_nan=True)
+        want = co.bulk_tail(x)
+        for a, b, nm in zip(outs["1"], want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+            assert_close(a, b, RTOL64 if dtype == np.float64 else 1e-6, f"{nm} {D}x{C} {np.dtype(dtype).name}")

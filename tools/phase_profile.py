@@ -27,8 +27,18 @@ NAMES = {0: "load x -> registers", 1: "rank x (tail)", 2: "series bulk (moments+
          7: "  zseries: finalize"}
 
 
+NAMES_Q = {13: "  rank: partition pass", 14: "  rank: round load + local histogram", 15: "  rank: round prefix",
+           7: "  rank: round output (scores / tags)", 11: "  rank: round placement", 12: "  rank: round count (+ sorted copy)"}
+
+
+NAMES_F = {13: "  fold merge: tile boundaries", 14: "  fold merge: staging (loads, fold, LDS stores)", 15: "  fold merge: diagonal search + merge",
+           7: "  fold merge: moment atomics"}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--f", action="store_true", help="the library was built with -DMDT_PROF_F: the z-series sub-slots are lent to fold_merge_phase")
+    ap.add_argument("--q", action="store_true", help="the library was built with -DMDT_PROF_Q: the z-series sub-slots are lent to the rank phase")
     ap.add_argument("--params", type=int, default=2560)
     ap.add_argument("--draws", type=int, default=10000)
     ap.add_argument("--chains", type=int, default=4)
@@ -51,8 +61,9 @@ def main():
     ms = ev0.elapsed_time(ev1) / a.reps
     top = sum(buf[i] for i in range(16))  # every stamp advances the shared clock: the slots partition the time
     print(f"{a.draws}x{a.chains}x{a.params}: {ms:.3f} ms per call, {a.params / ms * 1e3:.0f} param-series/s")
-    for i in sorted(NAMES):
-        print(f"{NAMES[i]:42s} {100.0 * buf[i] / top:6.2f} %")
+    names = {**NAMES, **NAMES_Q} if a.q else ({**NAMES, **NAMES_F} if a.f else NAMES)
+    for i in sorted(names):
+        print(f"{names[i]:42s} {100.0 * buf[i] / top:6.2f} %")
 
 
 if __name__ == "__main__":
