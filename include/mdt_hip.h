@@ -10,8 +10,11 @@
  * (paths relative to the reference repository).
  *
  * Conventions
- *   - arrays are dense, column-major, shaped (draws, chains, params): x[d + draws*(c + chains*p)]
- *     -- exactly the memory of a Julia Array{T,3}; outputs have `params` elements of dtype T;
+ *   - arrays are column-major, shaped (draws, chains, params): x[d + chain_stride*c + param_stride*p] with the
+ *     draws of one chain contiguous; the strides default (0) to the dense Julia Array{T,3},
+ *     chain_stride = draws, param_stride = draws*chains; (iterations, parameters, chains) storage as MCMCChains
+ *     keeps it is chain_stride = draws*params, param_stride = draws, read in place (src/utils.jl:203-211 only
+ *     ever takes views); outputs have `params` elements of dtype T;
  *   - every function returns an int status: MDT_OK or one of the MDT_E* codes; the message for
  *     the last failing call on a context is available from mdt_last_error();
  *   - `location` says whether x / outputs are host pointers (the library stages them through its
@@ -19,7 +22,10 @@
  *   - a context is single-owner: one call at a time; distinct contexts may be used from distinct
  *     host threads.  With `sync != 0` (what Julia wants: it reads the results immediately) the
  *     call returns after the stream has drained; with `sync == 0` and device pointers the work
- *     is only enqueued on `stream`;
+ *     is only enqueued on `stream`; conditions that a synchronous call reports as an error (a NaN under a
+ *     quantile, a slice too large for the ranking tables) are then kept as sticky flags on the context:
+ *     mdt_ctx_status() returns them;
+ *   - no entry point changes the calling thread's current HIP device;
  *   - no exceptions cross the boundary; NaN inputs propagate as in the reference
  *     (constant parameter -> NaN ESS and NaN R-hat, test/ess_rhat.jl:242-257).
  */
@@ -32,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDT_VERSION 100 /* 0.1.0 */
+#define MDT_VERSION 200 /* 0.2.0: mdt_args gained chain_stride / param_stride; mdt_ctx_status; mdt_ctx_create_multi */
 
 /* status codes (the Julia shim maps them to the reference's exception types) */
 #define MDT_OK 0
@@ -84,14 +90,40 @@ typedef struct mdt_args {
     int64_t maxlag;                /* keyword maxlag (default 250) */
     double tail_prob;              /* keyword tail_prob (default 1//10) */
     void* stream;                  /* hipStream_t to enqueue on, or NULL for the default stream */
+    int64_t chain_stride;          /* elements between the first draws of consecutive chains; 0: draws */
+    int64_t param_stride;          /* elements between consecutive parameters; 0: draws*chains */
 } mdt_args;
 
 int mdt_version(void);
 
-/* context life cycle; device_id is the HIP device ordinal (one context per GPU per process) */
+/* context life cycle; device_id is the HIP device ordinal (one context per GPU and stream per process) */
 int mdt_ctx_create(mdt_ctx** out, int device_id);
 int mdt_ctx_destroy(mdt_ctx* ctx);
 const char* mdt_last_error(const mdt_ctx* ctx);
+
+/*
+ * One context over several GPUs of the node: every parameter is independent (the `for` over
+ * _eachparam, src/ess_rhat.jl:517), so mdt_ess_rhat / mdt_bulk_tail / mdt_rhat_nested / mdt_mcse_mean on such a
+ * context cut the params axis into ndev contiguous blocks (block i = params [i*P/ndev, (i+1)*P/ndev)), run block
+ * i on device_ids[i] concurrently (one host thread and one stream per device, no exchange during compute) and
+ * leave every output vector complete in the caller's buffer.  location == MDT_HOST: each block is staged to its
+ * own GPU over PCIe.  location == MDT_DEVICE: x and the outputs live on ONE of the devices (found from the
+ * pointer); the other devices fetch their block and return their results by peer copies over xGMI.
+ * Calls on a multi-GPU context are synchronous on return.  Dense layout only (strides 0).  ndev == 1 is allowed.
+ */
+int mdt_ctx_create_multi(mdt_ctx** out, const int* device_ids, int ndev);
+
+/* flags of mdt_ctx_status */
+#define MDT_FLAG_RANK_OVERFLOW 1 /* draws*chains exceeded the ranking tables: the outputs of that parameter are NaN */
+#define MDT_FLAG_NAN_QUANTILE 2  /* a quantile of data containing NaN (Statistics.quantile throws ArgumentError, used at src/ess_rhat.jl:655); the ESS is NaN */
+#define MDT_FLAG_FDIST 4         /* gelmandiag: FDist would reject its parameter */
+/*
+ * Waits for the work enqueued through this context and returns the sticky condition flags raised by any launch
+ * since the last clearing call -- the way a caller of sync == 0 requests learns what a synchronous call would have
+ * returned as MDT_EARG / MDT_EUNSUPPORTED.  clear != 0 resets them.  A synchronous call that reports such an
+ * error itself also clears the flag it reported.
+ */
+int mdt_ctx_status(mdt_ctx* ctx, int32_t* flags, int32_t clear);
 
 /*
  * ess / rhat / ess_rhat  -- replaces src/ess_rhat.jl:276-311 (ess), :335-420 (rhat), :438-624

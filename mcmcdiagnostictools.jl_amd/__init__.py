@@ -24,5 +24,9 @@ from .api import (  # noqa: F401
     rank_normalize,
     rhat,
     rhat_nested,
+    status,
+    FLAG_RANK_OVERFLOW,
+    FLAG_NAN_QUANTILE,
+    FLAG_FDIST,
 )
 from .dist import ess_rhat_sharded, shard_bounds  # noqa: F401

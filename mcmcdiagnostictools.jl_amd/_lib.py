@@ -5,6 +5,7 @@ entry point raises.  Build with `python -c "import __graft_entry__ as g; g.build
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MDT_LIB: another build of the same library (A/B timing, diagnostics builds); never a different implementation
@@ -17,7 +18,7 @@ KIND = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3, "median": 4, "std": 5, "mad
 OUT_ESS, OUT_RHAT = 1, 2
 
 # every symbol include/mdt_hip.h declares
-SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_destroy", "mdt_last_error", "mdt_ess_rhat",
+SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_create_multi", "mdt_ctx_destroy", "mdt_ctx_status", "mdt_last_error", "mdt_ess_rhat",
            "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile", "mdt_rank_normalize", "mdt_layout_from_dpc",
            "mdt_bfmi", "mdt_gelmandiag", "mdt_debug_phase_cycles", "mdt_debug_beta")
 
@@ -38,6 +39,8 @@ class MdtArgs(ctypes.Structure):
         ("maxlag", ctypes.c_int64),
         ("tail_prob", ctypes.c_double),
         ("stream", ctypes.c_void_p),
+        ("chain_stride", ctypes.c_int64),
+        ("param_stride", ctypes.c_int64),
     ]
 
 
@@ -73,6 +76,8 @@ def load():
         ap = ctypes.POINTER(MdtArgs)
         lib.mdt_version.restype = ctypes.c_int
         lib.mdt_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
+        lib.mdt_ctx_create_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
+        lib.mdt_ctx_status.argtypes = [vp, ctypes.POINTER(i32), i32]
         lib.mdt_ctx_destroy.argtypes = [vp]
         lib.mdt_last_error.argtypes = [vp]
         lib.mdt_last_error.restype = ctypes.c_char_p
@@ -94,28 +99,60 @@ def load():
 
 
 _ctxs = {}
+_locks = {}
+_ctxs_lock = threading.Lock()
 MAX_CTX_PER_DEVICE = 4  # every context owns ~0.5 GB of per-workgroup scratch at the config-2 slice size
+FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = 1, 2, 4
 
 
 def ctx(device, stream=None):
     """One mdt_ctx per (GPU, stream) per process.  A context owns the scratch its kernels work in, so requests that
     may run concurrently -- different streams -- must not share one; requests on one stream are ordered and do.
     At most MAX_CTX_PER_DEVICE live per GPU: the least recently created one (never the default stream's) is
-    destroyed first (mdt_ctx_destroy synchronises the device)."""
+    destroyed first (mdt_ctx_destroy synchronises the device).  `device` may be a tuple of device ordinals: one
+    multi-GPU context (mdt_ctx_create_multi) per tuple."""
     lib = load()
-    key = (int(device), int(stream or 0))
-    if key not in _ctxs:
-        mine = [k for k in _ctxs if k[0] == key[0]]
-        if len(mine) >= MAX_CTX_PER_DEVICE:
-            victim = next(k for k in mine if k[1] != 0)
-            lib.mdt_ctx_destroy(_ctxs.pop(victim))
-        h = ctypes.c_void_p()
-        rc = lib.mdt_ctx_create(ctypes.byref(h), int(device))
-        if rc != MDT_OK:
-            raise MdtRuntimeError(f"mdt_ctx_create(device={device}) failed with status {rc} "
-                                  "(no MI355X visible? there is no CPU fallback)")
-        _ctxs[key] = h
-    return _ctxs[key]
+    multi = isinstance(device, (tuple, list))
+    key = (tuple(int(d) for d in device), 0) if multi else (int(device), int(stream or 0))
+    with _ctxs_lock:
+        if key not in _ctxs:
+            h = ctypes.c_void_p()
+            if multi:
+                ids = (ctypes.c_int * len(key[0]))(*key[0])
+                rc = lib.mdt_ctx_create_multi(ctypes.byref(h), ids, len(key[0]))
+            else:
+                mine = [k for k in _ctxs if k[0] == key[0]]
+                if len(mine) >= MAX_CTX_PER_DEVICE:
+                    victim = next(k for k in mine if k[1] != 0)
+                    with _locks[victim]:
+                        lib.mdt_ctx_destroy(_ctxs.pop(victim))
+                    del _locks[victim]
+                rc = lib.mdt_ctx_create(ctypes.byref(h), int(device))
+            if rc != MDT_OK:
+                raise MdtRuntimeError(f"mdt_ctx_create(device={device}) failed with status {rc} "
+                                      "(no MI355X visible? there is no CPU fallback)")
+            _ctxs[key] = h
+            _locks[key] = threading.Lock()
+        return _ctxs[key]
+
+
+def lock(h):
+    """the lock of a context: an mdt_ctx is single-owner (include/mdt_hip.h), ctypes releases the GIL during a call,
+    so two Python threads on the same (device, stream) must not enter the library together"""
+    with _ctxs_lock:
+        for k, v in _ctxs.items():
+            if v.value == h.value:
+                return _locks[k]
+    return threading.Lock()
+
+
+def status(h, clear=True):
+    """sticky condition flags of the context (mdt_ctx_status): what asynchronous requests could not report"""
+    f = ctypes.c_int32(0)
+    with lock(h):
+        rc = load().mdt_ctx_status(h, ctypes.byref(f), 1 if clear else 0)
+    check(rc, h)
+    return int(f.value)
 
 
 def check(rc, h):

@@ -128,8 +128,18 @@ def _prepare(samples):
         P *= d
     pr.D, pr.C, pr.P = D, C, P
     x3 = samples.reshape(D, C, P)
+    pr.cs = pr.ps = 0  # chain_stride / param_stride in elements; 0 = dense (draws, chains, params)
     if is_torch:
-        xt = x3.permute(2, 1, 0).contiguous()  # no copy when memory is already draws-fastest
+        st = x3.stride() if D * C * P > 0 else (1, D, D * C)
+        dense = (st[0] == 1 or D == 1) and (st[1] == D or C == 1) and (st[2] == D * C or P == 1)
+        if x3.is_cuda and not dense and (st[0] == 1 or D == 1) and (st[1] >= D or C == 1) and (st[2] >= 1 or P == 1):
+            # draws contiguous, chains / parameters strided (e.g. MCMCChains' (iterations, parameters, chains)
+            # storage viewed as (draws, chains, params)): read in place through the strides of mdt_args
+            pr.cs = int(st[1]) if C > 1 else D
+            pr.ps = int(st[2]) if P > 1 else max(1, (C - 1) * pr.cs + D)
+            xt = x3
+        else:
+            xt = x3.permute(2, 1, 0).contiguous()  # no copy when memory is already draws-fastest
         pr.dev = xt.is_cuda
         pr.device_index = xt.device.index if xt.is_cuda else 0
         pr.buf = xt
@@ -173,13 +183,37 @@ def _args(pr, kind, outputs, autocov, split_chains, maxlag, relative, tail_prob,
         stream = torch.cuda.current_stream(pr.buf.device).cuda_stream
     return _lib.MdtArgs(pr.D, pr.C, pr.P, _lib.MDT_F32 if pr.f32 else _lib.MDT_F64,
                         _lib.MDT_DEVICE if pr.dev else _lib.MDT_HOST, kind, outputs, autocov, int(split_chains),
-                        1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream)
+                        1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream,
+                        getattr(pr, "cs", 0), getattr(pr, "ps", 0))
 
 
-def _ctx(pr):
-    """the context of (device, current stream): concurrent streams never share scratch"""
+def _ctx(pr, devices=None):
+    """the context of (device, current stream): concurrent streams never share scratch.  `devices`: a sequence of
+    GPU ordinals -> the multi-GPU context over them (params axis cut into contiguous blocks, mdt_ctx_create_multi)"""
+    if devices is not None:
+        return _lib.ctx(tuple(int(d) for d in devices))
     stream = torch.cuda.current_stream(pr.buf.device).cuda_stream if pr.dev else 0
     return _lib.ctx(pr.device_index if pr.dev else 0, stream)
+
+
+def _call(h, fn, *args):
+    """one library call on context h: under the context's lock (an mdt_ctx is single-owner), status -> exception"""
+    with _lib.lock(h):
+        rc = fn(h, *args)
+    _lib.check(rc, h)
+
+
+def status(device=None, *, devices=None, clear=True):
+    """Sticky condition flags of the context of (device, current stream) -- or of the multi-GPU context over
+    `devices` -- after waiting for its queued work (mdt_ctx_status): what requests issued with sync=False could not
+    raise.  Bits: FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE (the reference throws ArgumentError there), FLAG_FDIST."""
+    if devices is not None:
+        return _lib.status(_lib.ctx(tuple(int(d) for d in devices)), clear)
+    dev = torch.cuda.current_device() if device is None else int(device)
+    return _lib.status(_lib.ctx(dev, torch.cuda.current_stream(dev).cuda_stream), clear)
+
+
+FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = _lib.FLAG_RANK_OVERFLOW, _lib.FLAG_NAN_QUANTILE, _lib.FLAG_FDIST
 
 
 def _finish(pr, out):
@@ -218,7 +252,7 @@ def _warn_niter(pr, split_chains):
 
 
 def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_method=None, split_chains=2,
-                   maxlag=250, tail_prob=0.1, sync=True):
+                   maxlag=250, tail_prob=0.1, sync=True, devices=None):
     split_chains = _check_int("split_chains", split_chains)
     maxlag = _check_int("maxlag", maxlag)
     if split_chains < 1:
@@ -230,11 +264,10 @@ def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_m
     ess_o = _new_out(pr) if want_ess else None
     rhat_o = _new_out(pr) if want_rhat else None
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx(pr, devices)
         a = _args(pr, _lib.KIND[kind], (1 if want_ess else 0) | (2 if want_rhat else 0), autocov, split_chains,
                   maxlag, relative, tail_prob, sync)
-        rc = _lib.load().mdt_ess_rhat(h, ctypes.byref(a), pr.ptr, _optr(ess_o), _optr(rhat_o))
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_ess_rhat, ctypes.byref(a), pr.ptr, _optr(ess_o), _optr(rhat_o))
     return pr, ess_o, rhat_o
 
 
@@ -260,12 +293,12 @@ def ess(samples, *, kind="bulk", **kwargs):
     raise ArgumentError(f"the estimator {kind} is not yet supported by `ess`")
 
 
-def rhat(samples, *, kind="rank", split_chains=2):
+def rhat(samples, *, kind="rank", split_chains=2, devices=None):
     """R-hat (src/ess_rhat.jl:335-420)."""
     kind = _norm_kind(kind)
     if kind not in _KINDS:
         raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat`")
-    pr, _, r = _call_ess_rhat(samples, kind, False, True, split_chains=split_chains)
+    pr, _, r = _call_ess_rhat(samples, kind, False, True, split_chains=split_chains, devices=devices)
     return _finish(pr, r)
 
 
@@ -278,21 +311,40 @@ def ess_rhat(samples, *, kind="rank", **kwargs):
     return ESSRhat(_finish(pr, e), _finish(pr, r))
 
 
+def _check_out(pr, out, n=4):
+    """caller-supplied output buffers of bulk_tail: the library writes pr.P elements of the input's dtype through the
+    raw pointers, so count, shape, dtype, contiguity and placement are checked here"""
+    if len(out) != n:
+        raise ArgumentError(f"`out` must hold {n} buffers, got {len(out)}")
+    for o in out:
+        if pr.torch:
+            ok = isinstance(o, torch.Tensor) and o.dim() == 1 and o.is_contiguous() and o.numel() == pr.P and \
+                o.dtype == (torch.float32 if pr.f32 else torch.float64) and o.device == pr.buf.device
+        else:
+            ok = isinstance(o, np.ndarray) and o.ndim == 1 and o.flags.c_contiguous and o.size == pr.P and \
+                o.dtype == (np.float32 if pr.f32 else np.float64)
+        if not ok:
+            raise DimensionMismatch(f"every `out` buffer must be a contiguous 1-d array of {pr.P} "
+                                    f"{'float32' if pr.f32 else 'float64'} values in the same memory (host / GPU) as `samples`")
+
+
 def bulk_tail(samples, *, relative=False, autocov_method=None, split_chains=2, maxlag=250, tail_prob=0.1,
-              sync=True, out=None):
+              sync=True, out=None, devices=None):
     """The BASELINE metric in one pass: ess_rhat(kind=:bulk) and ess_rhat(kind=:tail) fused.
-    Returns (ess_bulk, ess_tail, rhat_bulk, rhat_tail)."""
+    Returns (ess_bulk, ess_tail, rhat_bulk, rhat_tail).  `out`: four 1-d buffers to write into (validated);
+    `devices`: run on the multi-GPU context over these ordinals (params axis in contiguous blocks)."""
     split_chains = _check_int("split_chains", split_chains)
     maxlag = _check_int("maxlag", maxlag)
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
     pr = _prepare(samples)
     _warn_niter(pr, split_chains)
+    if out is not None:
+        _check_out(pr, out)
     outs = out if out is not None else [_new_out(pr) for _ in range(4)]
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx(pr, devices)
         a = _args(pr, 0, 3, autocov, split_chains, maxlag, relative, tail_prob, sync)
-        rc = _lib.load().mdt_bulk_tail(h, ctypes.byref(a), pr.ptr, *[_optr(o) for o in outs])
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_bulk_tail, ctypes.byref(a), pr.ptr, *[_optr(o) for o in outs])
     if out is not None:
         return out
     return tuple(_finish(pr, o) for o in outs)
@@ -315,7 +367,7 @@ def _validate_superchain_ids(superchain_ids, nchains):
     return np.asfortranarray(np.array([groups[k] for k in keys], dtype=np.int32).T)
 
 
-def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
+def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, devices=None):
     """Nested R-hat (src/rhat_nested.jl:43-188)."""
     nd = samples.ndim if hasattr(samples, "ndim") else np.asarray(samples).ndim
     if nd < 2:
@@ -328,11 +380,10 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2):
     pr = _prepare(samples)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx(pr, devices)
         a = _args(pr, _lib.KIND[kind], 2, 0, split_chains, 250, False, 0.1)
         K, S = inds.shape
-        rc = _lib.load().mdt_rhat_nested(h, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(out))
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_rhat_nested, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(out))
     return _finish(pr, out)
 
 
@@ -347,13 +398,14 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     maxlag = _check_int("maxlag", kwargs.pop("maxlag", 250))
     autocov = _autocov_code(kwargs.pop("autocov_method", AutocovMethod()))
     relative = kwargs.pop("relative", False)
+    devices = kwargs.pop("devices", None)
     if kwargs:
         raise TypeError(f"unsupported keyword arguments {sorted(kwargs)}")
     pr = _prepare(samples)
     _warn_niter(pr, split_chains)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx(pr, devices)
         lib = _lib.load()
         if est is None or est[0] == "std":
             a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
@@ -361,8 +413,7 @@ def mcse(samples, *, kind=np.mean, **kwargs):
         else:
             a = _args(pr, _lib.KIND[est[0]], 1, autocov, split_chains, maxlag, relative, est[1])
             fn = lib.mdt_mcse_quantile
-        rc = fn(h, ctypes.byref(a), pr.ptr, _optr(out))
-        _lib.check(rc, h)
+        _call(h, fn, ctypes.byref(a), pr.ptr, _optr(out))
     return _finish(pr, out)
 
 
@@ -376,8 +427,7 @@ def rank_normalize(samples, *, fold=False, want_ranks=True):
     if pr.P > 0:
         h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
-        rc = _lib.load().mdt_rank_normalize(h, ctypes.byref(a), pr.ptr, 1 if fold else 0, _optr(ranks), _optr(z))
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_rank_normalize, ctypes.byref(a), pr.ptr, 1 if fold else 0, _optr(ranks), _optr(z))
 
     def back(o):
         if o is None:
@@ -406,8 +456,7 @@ def from_mcmcchains_layout(samples):
     pr.device_index = samples.device.index or 0
     h = _ctx(pr)
     a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
-    rc = _lib.load().mdt_layout_from_dpc(h, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
-    _lib.check(rc, h)
+    _call(h, _lib.load().mdt_layout_from_dpc, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
     return out.permute(2, 1, 0)
 
 
@@ -437,8 +486,7 @@ def bfmi(energy, *, dims=1):
     if pr.C > 0:
         h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
-        rc = _lib.load().mdt_bfmi(h, ctypes.byref(a), pr.ptr, _optr(out))
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_bfmi, ctypes.byref(a), pr.ptr, _optr(out))
     return float(out[0]) if e.ndim == 1 else out
 
 
@@ -456,6 +504,5 @@ def gelmandiag(samples, *, alpha=0.05):
     if pr.P > 0:
         h = _ctx(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
-        rc = _lib.load().mdt_gelmandiag(h, ctypes.byref(a), pr.ptr, float(alpha), _optr(psrf), _optr(ci))
-        _lib.check(rc, h)
+        _call(h, _lib.load().mdt_gelmandiag, ctypes.byref(a), pr.ptr, float(alpha), _optr(psrf), _optr(ci))
     return GelmanDiag(psrf, ci)

@@ -108,6 +108,9 @@ static_assert(LDS_RANK_END <= LDS_BYTES && LDS_SER_END <= LDS_BYTES && LDS_IND_E
 namespace mdtc {
 struct KP {
     const void* x;
+    long long cstride, pstride; // elements between chains / parameters of x (dense: D, D*C)
+    int strided;                // x is not dense: every workgroup gathers its parameter into xcbuf first
+    void* xcbuf;                // per-workgroup scratch for that, stride n_pad elements of T
     long long D, C, P, n;       // draws, chains, params, n = D*C
     long long niter;            // D / s
     int s, rem, m;              // split_chains, D % s, m = C*s
@@ -142,7 +145,7 @@ struct KP {
     void* z_out;                // stage: [P*n] normal scores (T)
     const int* chain_inds;      // nested: K x S (device)
     int K, S;
-    int* status;                // device status words: [0] bit0 rounds overflow, bit1 NaN hit quantile; [1] next-parameter ticket
+    int* status;                // device status words: [0] flags of this launch (bit0 rounds overflow, bit1 NaN hit quantile, bit2 FDist); [1] next-parameter ticket; [2] sticky flags of earlier launches
     unsigned long long* prof;   // optional [grid*16] phase cycle counters (diagnostics), or null
 };
 } // namespace mdtc
@@ -432,6 +435,8 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
 
 #include "mdt_indicator.inc"
 
+#include "mdt_nested.inc"
+
 // ------------------------------------------------------------------ the kernel
 template <typename T>
 __device__ __forceinline__ void store_out(void* p, long long i, double v) {
@@ -469,50 +474,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const long long p = (long long)uni(*tick); // wave-uniform: every branch on p is a scalar branch
         __syncthreads();
         if (p >= kp.P) break;
-        const T* __restrict__ xp = (const T*)kp.x + p * n;
+        const T* xp = (const T*)kp.x + p * (kp.strided ? kp.pstride : n);
+        if (kp.strided) {
+            // x[d + cstride * c + pstride * p] (e.g. MCMCChains' (iterations, parameters, chains) storage, read in place):
+            // the chains of this parameter are gathered -- each a coalesced stream -- into the workgroup's own dense
+            // scratch slice, which stays cache-resident for the passes that follow
+            T* xc = (T*)kp.xcbuf + (long long)blockIdx.x * kp.n_pad;
+            const unsigned uD = (unsigned)D;
+            for (unsigned e = (unsigned)tid; e < (unsigned)n; e += NT) {
+                const unsigned c = e / uD, d = e - c * uD;
+                xc[e] = xp[(long long)c * kp.cstride + d];
+            }
+            __syncthreads();
+            xp = xc;
+        }
+        if (tid == 0) ((int*)(smem + OFF_INTS))[19] = 0; // set when the ranking tables overflow: the parameter's outputs become NaN
+        const bool many = kp.m > MAXM; // more split chains than the LDS moment tables hold: R-hat only (rhat_many_phase)
         const SrcPlain<T> VX{(const MDT_GA T*)xp};
         const SerX<T> YX{(const MDT_GA T*)xp, D};
         const SerZ YZ{(const MDT_GA double*)zb, D};
         const bool zfast = (kp.niter + kp.maxlag + 40 <= SZ) && (kp.maxlag < SZ_EDGE);
-
-        // nested R-hat combine from mean_j / var_j (src/rhat_nested.jl:152-184); lane 0 only
-        auto nested_combine = [&]() -> double {
-            const int K = kp.K, S = kp.S, s = kp.s;
-            const int mk = K * s;
-            double within = 0.0, smean_sum = 0.0;
-            for (int k = 0; k < S; ++k) {
-                double ms = 0.0, Wk = 0.0;
-                for (int i = 0; i < K; ++i) {
-                    const int c = kp.chain_inds[k * K + i];
-                    for (int q = 0; q < s; ++q) { ms += mean_j[c * s + q]; Wk += var_j[c * s + q]; }
-                }
-                ms /= (double)mk;
-                Wk /= (double)mk;
-                double Bk = 0.0;
-                for (int i = 0; i < K; ++i) {
-                    const int c = kp.chain_inds[k * K + i];
-                    for (int q = 0; q < s; ++q) { const double d = mean_j[c * s + q] - ms; Bk = fma(d, d, Bk); }
-                }
-                Bk /= (double)(mk > 1 ? mk - 1 : mk);
-                within += Wk + Bk;
-                smean_sum += ms;
-            }
-            within /= (double)S;
-            const double sm = smean_sum / (double)S;
-            double between = 0.0;
-            for (int k = 0; k < S; ++k) {
-                double ms = 0.0;
-                for (int i = 0; i < K; ++i) {
-                    const int c = kp.chain_inds[k * K + i];
-                    for (int q = 0; q < s; ++q) ms += mean_j[c * s + q];
-                }
-                ms /= (double)mk;
-                const double d = ms - sm;
-                between = fma(d, d, between);
-            }
-            between /= (double)(S - 1);
-            return sqrt(1.0 + between / within);
-        };
 
         if (kp.niter == 0) { // mean of nothing: everything is NaN (src/ess_rhat.jl:391-406 with niter = 0)
             if (tid == 0) {
@@ -586,6 +567,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // rhat(x) and ess_rhat(x).rhat are the same bits; then the autocovariance: the in-LDS FFT if asked
             // for, the one-chain-per-LDS-buffer sweep when a split chain fits, the tiled series_phase otherwise
             const bool acov = kp.need_eb && kp.ess_ok;
+            if (many) { // (R-hat or nested R-hat of the raw draws; the host refuses ESS with this many chains)
+                const double r = rhat_many_phase<T>(kp, xp, xs, smem);
+                if (tid == 0) { store_out<T>(kp.out_eb, p, nan); store_out<T>(kp.out_rb, p, r); }
+                __syncthreads();
+                continue;
+            }
             SeriesOut so = series_z_phase<false, true, T>(kp, xp, nullptr, false, smem);
             if (acov) {
                 SeriesOut sa;
@@ -596,7 +583,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             }
             double ess = acov ? so.ess : nan;
             if (kp.mode == 1) {
-                if (tid == 0) store_out<T>(kp.out_rb, p, nested_combine());
+                const double r = nested_combine_wg(kp, mean_j, var_j, smem);
+                if (tid == 0) store_out<T>(kp.out_rb, p, r);
                 __syncthreads();
             } else if (kp.mode == 2) {
                 // pooled corrected std over all draws and chains (src/mcse.jl:50)
@@ -747,7 +735,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             SeriesOut so;
             // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
             // bits whichever autocovariance path follows
-            if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat)
+            if (many) { // time-order scores, one thread per split chain
+                so.rhat = rhat_many_phase<double>(kp, zb, xs, smem); so.ess = nan;
+            } else if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat)
                 so.rhat = nan; so.ess = nan;
             } else if (acov && fft_lds) {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
@@ -760,14 +750,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 so = series_phase(kp, YZ, true, smem, true);
                 so.ess = fft_const_chain_nan(so.ess);
             }
-            rb = (kp.mode == 1) ? 0.0 : so.rhat;
+            rb = so.rhat;
             if (acov) eb = so.ess;
-            if (kp.mode == 1) {
-                if (tid == 0) scal[20] = nested_combine();
-                __syncthreads();
-                rb = scal[20];
-                __syncthreads();
-            }
+            if (kp.mode == 1 && !many) rb = nested_combine_wg(kp, mean_j, var_j, smem);
         }
         MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
@@ -777,7 +762,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             MDT_PROF_MARK(PH_RANKF);
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
             // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores
-            if (rk == 3) {
+            if (many) {
+                rt = rhat_many_phase<double>(kp, zb, xs, smem);
+            } else if (rk == 3) {
                 if (tid == 0) series_combine(kp, smem, 0, 1, false);
                 __syncthreads();
                 rt = scal[2];
@@ -785,12 +772,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             } else {
                 rt = series_z_phase<false>(kp, zb, nullptr, false, smem).rhat;
             }
-            if (kp.mode == 1) {
-                if (tid == 0) scal[20] = nested_combine();
-                __syncthreads();
-                rt = scal[20];
-                __syncthreads();
-            }
+            if (kp.mode == 1 && !many) rt = nested_combine_wg(kp, mean_j, var_j, smem);
             MDT_PROF_MARK(PH_SERT);
         }
         if (kp.need_et && kp.ess_ok) {
@@ -800,6 +782,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem);
             MDT_PROF_MARK(PH_IND);
         }
+        if (((int*)(smem + OFF_INTS))[19]) { eb = nan; rb = nan; et = nan; rt = nan; } // ranking tables overflowed (status bit 0)
         if (tid == 0) {
             store_out<T>(kp.out_eb, p, eb);
             store_out<T>(kp.out_rb, p, rb);

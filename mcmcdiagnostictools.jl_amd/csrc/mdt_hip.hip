@@ -73,7 +73,15 @@ struct mdt_ctx {
     long long ztab_n = -1;
     int ztab_f32 = -1;
     long long ztab_cap = 0;
-    // status word + nested chain indices
+    // several GPUs of one node (mdt_ctx_create_multi): one child context per device, params cut into contiguous blocks
+    std::vector<mdt_ctx*> children;
+    // the stream the last request went to (a context serves one stream at a time; mdt_ctx_status waits on it)
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    // strided input: per-workgroup dense copy of the parameter being worked on
+    void* xcbuf = nullptr;
+    long long xc_elems = 0;
+    // status words (flags of the launch, ticket, sticky flags) + nested chain indices
     int* status = nullptr;
     unsigned long long* prof = nullptr; // [2*grid*16] phase cycle counters when MDT_PROF is set
     KP* kp_ring = nullptr;              // device copies of the kernel parameters, one slot per launch
@@ -95,6 +103,21 @@ struct mdt_ctx {
 };
 
 namespace {
+
+// no entry point leaves the calling thread on another device than it came with (PyTorch and HIP.jl read the
+// current device from the runtime)
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define MDT_ON_DEVICE(ctx)                                                                     \
+    DeviceGuard guard_((ctx)->device);                                                         \
+    if (!guard_.ok) return fail((ctx), MDT_ERUNTIME, "hipSetDevice failed")
 
 // (draws, params, chains) -> (draws, chains, params): both sides are runs of `draws` contiguous values
 template <typename T>
@@ -259,15 +282,23 @@ __global__ __launch_bounds__(64) void mcse_quantile_pos_kernel(const T* __restri
 }
 
 // Launch prologue on the compute queue: the parameter block arrives as a kernel argument and is stored into its
-// ring slot, the ticket (and, unless a first pass left flags to report, the status word) is cleared.  One small
+// ring slot, the ticket (and, unless a first pass left flags to report, the status word) is cleared.  Everything is
+// ordered by the stream, so a slot is never rewritten while a launch that reads it is still queued in front.  One small
 // kernel instead of a memset and a host-to-device copy: no hand-over between the copy engine and the compute
 // queue in front of every launch.
 __global__ void kp_setup_kernel(KP* slot, KP v, int* status, int keep_status) {
     if (threadIdx.x == 0) {
         *slot = v;
-        if (!keep_status) status[0] = 0;
+        // the flags of the previous launch become sticky (mdt_ctx_status) before this launch starts with a clean word;
+        // a second pass keeps the word: its caller reports the flags of both passes
+        if (!keep_status) { status[2] |= status[0]; status[0] = 0; }
         status[1] = 0;
     }
+}
+
+// the same bookkeeping for the entry points that do not go through mdt_kernel (gelmandiag)
+__global__ void status_begin_kernel(int* status) {
+    if (threadIdx.x == 0) { status[2] |= status[0]; status[0] = 0; status[1] = 0; }
 }
 
 constexpr unsigned KP_RING = 64;
@@ -291,6 +322,7 @@ int ensure_scratch(mdt_ctx* ctx, long long n, long long wgs) {
     const long long n_pad = ((n + 63) / 64) * 64;
     const long long need = wgs * n_pad;
     if (need > ctx->scratch_elems) {
+        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream)); // launches still queued work in the old buffers
         if (ctx->r2buf) (void)hipFree(ctx->r2buf);
         if (ctx->binbuf) (void)hipFree(ctx->binbuf);
         if (ctx->zbuf) (void)hipFree(ctx->zbuf);
@@ -362,9 +394,12 @@ struct Req {
     int keep_status = 0; // second pass of a two-pass request: the flags of the first pass are still to be reported
 };
 
+int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq);
+
 int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (!ctx) return MDT_EARG;
     if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (!ctx->children.empty()) return run_multi(ctx, a, x, rq);
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
     if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
@@ -375,6 +410,10 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (!x) return fail(ctx, MDT_EARG, "x is NULL");
     if (D == 0 || C == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
     const long long n = D * C, niter = D / s, m = C * s;
+    // layout: x[d + cs * c + ps * p]; 0 = dense
+    const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : n;
+    if (cs < D || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
+    const bool strided = !(cs == D && ps == n);
     const int ess_ok = niter > 4;
     long long maxlag = a->maxlag;
     if (rq.want_ess && ess_ok) {
@@ -388,7 +427,12 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         return fail(ctx, MDT_EARG, "quantile probability must be in [0, 1]"); // Statistics.quantile
     // engine limits
     static_assert(mdt_big::MAXM == mdt_small::MAXM && mdt_big::MAXM == mdt_tiny::MAXM, "one limit for all geometries");
-    if (m > mdt_big::MAXM) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 is not supported");
+    // more split chains than the LDS moment tables hold (many short chains, what nested R-hat is for): R-hat and
+    // nested R-hat of any kind run with one thread per split chain (rhat_many_phase); ESS needs the tables
+    const bool many = m > mdt_big::MAXM;
+    if (many && (rq.want_ess || rq.est || (rq.mode != 0 && rq.mode != 1) || rq.need_eb || rq.need_et))
+        return fail(ctx, MDT_EUNSUPPORTED, "ESS with chains*split_chains > 256 is not supported (R-hat and nested R-hat are)");
+    if (many && 2 * m > n) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 needs at least 2*split_chains draws");
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     const bool indicators = rq.need_et || rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE;
@@ -412,10 +456,19 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
 
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     const size_t ts = tsize(a->dtype);
     const bool f32 = a->dtype == MDT_F32;
+    // a context serves one stream at a time: work queued on another stream may still use the scratch and the status words
+    if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    // nested R-hat: split chains per superchain and superchains the combine step holds in LDS
+    if (rq.mode == 1) {
+        const long long mkmax = tiny ? mdt_tiny::NEST_MK : mdt_small::NEST_MK, smax = tiny ? mdt_tiny::NEST_S : mdt_small::NEST_S;
+        static_assert(mdt_small::NEST_MK == mdt_big::NEST_MK && mdt_small::NEST_S == mdt_big::NEST_S, "one limit for the 80 / 160 KiB geometries");
+        if ((long long)rq.K * s > mkmax || rq.S > smax)
+            return fail(ctx, MDT_EUNSUPPORTED, "rhat_nested: more than 2048 split chains per superchain, or more than 2048 superchains (1024 for slices of <= 12288 values)");
+    }
 
     // host staging
     const void* dx = x;
@@ -423,12 +476,12 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     void* outs_dev[5] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank};
     double* rank_host = rq.rank_out; void* z_host = rq.z_out;
     if (a->location == MDT_HOST) {
-        const size_t xb = (size_t)n * P * ts;
+        const size_t xb = (size_t)((P - 1) * ps + (C - 1) * cs + D) * ts; // the extent of x, whatever lies between its pieces
         if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
         size_t ob = 5 * (size_t)P * ts;
-        if (rq.mode == 3) ob += (size_t)n * P * (8 + ts);
+        if (rq.mode == 3) ob += (size_t)n * P * (8 + ts) + 16; // (+ the 16-byte alignment of the stage arrays)
         if (int rcs = stage_out_bytes(ctx, ob)) return rcs;
         for (int i = 0; i < 5; ++i)
             outs_dev[i] = outs_host[i] ? (void*)((char*)ctx->stage_out + (size_t)i * P * ts) : nullptr;
@@ -443,6 +496,16 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const long long wgs = tiny ? 2LL * ctx->grid : (small ? ctx->grid : ctx->grid / 2);
     int rc = ensure_scratch(ctx, n, wgs);
     if (rc) return rc;
+    if (strided) {
+        const long long need = wgs * ctx->n_pad;
+        if (need > ctx->xc_elems) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
+            ctx->xcbuf = nullptr; ctx->xc_elems = 0;
+            HIP_TRY(hipMalloc(&ctx->xcbuf, (size_t)need * 8));
+            ctx->xc_elems = need;
+        }
+    }
     const bool need_rank = !rq.basic || rq.mode == 3;
     if (need_rank) {
         rc = ensure_ztab(ctx, n, f32 ? 1 : 0, st);
@@ -463,6 +526,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     KP kp;
     memset(&kp, 0, sizeof(kp));
     kp.x = dx;
+    kp.cstride = cs; kp.pstride = ps; kp.strided = strided ? 1 : 0; kp.xcbuf = ctx->xcbuf;
     kp.D = D; kp.C = C; kp.P = P; kp.n = n;
     kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
     kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est; kp.fft_lds = fft_lds ? 1 : 0;
@@ -511,6 +575,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // histogram + partition passes of the two-level variant cost more than re-streaming a slice that is
         // only one or two rounds long: 1000 x 4 x 100 000 takes 31.8 ms instead of 35.0, 200 x 4 x 500 000 132 instead of 161)
         kp.rank_variant = rv ? atoi(rv) : ((small || tiny) ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
+        // the round tables hold MAXROUNDS rounds of at most one LDS chunk each: beyond that the ranking cannot be served
+        // (slices between half of that and that may still overflow on the device: status flag, NaN outputs)
+        const long long chunk = tiny ? std::min(mdt_tiny::QCH, mdt_tiny::CH) : (small ? std::min(mdt_small::QCH, mdt_small::CH) : std::min(mdt_big::QCH, mdt_big::CH));
+        if (need_rank && n > (long long)mdt_big::MAXROUNDS * chunk)
+            return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
     }
     { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
@@ -531,10 +600,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
     const unsigned si = ctx->kp_next++ % KP_RING;
     KP* slot = ctx->kp_ring + si;
-    if (ctx->kp_next % KP_RING == 0) HIP_TRY(hipStreamSynchronize(st)); // never overwrite a slot still in flight
     hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
     HIP_TRY(hipGetLastError());
+    ctx->last_stream = st;
+    ctx->used = true;
 
     if (a->location == MDT_HOST) {
         for (int i = 0; i < 5; ++i)
@@ -548,9 +618,78 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         int status = 0;
         HIP_TRY(hipMemcpyAsync(&status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (status & 1) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
-        if (status & 2) return fail(ctx, MDT_EARG, "quantiles are undefined for collections containing NaNs"); // Statistics.quantile
+        if (status & 3) { // reported here: not left behind as a sticky flag
+            HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(int), st));
+            if (status & 1) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
+            return fail(ctx, MDT_EARG, "quantiles are undefined for collections containing NaNs"); // Statistics.quantile
+        }
     }
+    return MDT_OK;
+}
+
+// ---- several GPUs: the params axis in contiguous blocks, one host thread and one child context per device
+int run_shard(mdt_ctx* child, const mdt_args* a, const void* x, const Req& rq, long long lo, long long hi, int owner_dev) {
+    const long long n = a->draws * a->chains, cnt = hi - lo;
+    const size_t ts = tsize(a->dtype);
+    mdt_args b = *a;
+    b.params = cnt;
+    b.sync = 1;
+    const char* xs = (const char*)x + (size_t)lo * n * ts;
+    void* Req::*outs[5] = {&Req::out_eb, &Req::out_rb, &Req::out_et, &Req::out_rt, &Req::out_rrank};
+    Req r = rq;
+    if (a->location == MDT_HOST || child->device == owner_dev) {
+        for (auto o : outs) if (r.*o) r.*o = (char*)(r.*o) + (size_t)lo * ts;
+        if (a->location == MDT_HOST) b.stream = nullptr; // (the caller's stream belongs to one device at most)
+        return run(child, &b, xs, r);
+    }
+    // the block lives on another GPU: fetch it, work on the copy, send the results back (peer copies over xGMI)
+    mdt_ctx* ctx = child;
+    MDT_ON_DEVICE(child);
+    const size_t xb = (size_t)cnt * n * ts;
+    if (int rc = stage_x_bytes(child, xb)) return rc;
+    if (int rc = stage_out_bytes(child, 5 * (size_t)cnt * ts)) return rc;
+    HIP_TRY(hipMemcpyPeer(child->stage_x, child->device, xs, owner_dev, xb));
+    int k = 0;
+    for (auto o : outs) { if (r.*o) r.*o = (char*)child->stage_out + (size_t)k * cnt * ts; ++k; }
+    b.stream = nullptr;
+    if (int rc = run(child, &b, child->stage_x, r)) return rc;
+    k = 0;
+    for (auto o : outs) {
+        if (rq.*o) HIP_TRY(hipMemcpyPeer((char*)(rq.*o) + (size_t)lo * ts, owner_dev, (char*)child->stage_out + (size_t)k * cnt * ts, child->device, (size_t)cnt * ts));
+        ++k;
+    }
+    return MDT_OK;
+}
+
+int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq) {
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
+    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "a multi-GPU context takes the dense layout only");
+    if (rq.mode > 2 || rq.est || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
+    const long long P = a->params;
+    if (P == 0) return MDT_OK;
+    if (!x) return fail(ctx, MDT_EARG, "x is NULL");
+    const int nd = (int)ctx->children.size();
+    int owner_dev = -1;
+    if (a->location == MDT_DEVICE) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, x) != hipSuccess) return fail(ctx, MDT_EARG, "x is not a device pointer");
+        owner_dev = at.device;
+        DeviceGuard g(owner_dev);
+        if (!g.ok || hipStreamSynchronize((hipStream_t)a->stream) != hipSuccess) // the producers of x have finished
+            return fail(ctx, MDT_ERUNTIME, "cannot synchronise the stream of x");
+    }
+    std::vector<int> rcs(nd, MDT_OK);
+    std::vector<std::thread> th;
+    for (int i = 0; i < nd; ++i) {
+        const long long lo = (long long)i * P / nd, hi = (long long)(i + 1) * P / nd;
+        if (hi == lo) continue;
+        th.emplace_back([=, &rcs, &rq] { rcs[i] = run_shard(ctx->children[i], a, x, rq, lo, hi, owner_dev); });
+    }
+    for (auto& t : th) t.join();
+    for (int i = 0; i < nd; ++i)
+        if (rcs[i]) return fail(ctx, rcs[i], "device " + std::to_string(ctx->children[i]->device) + ": " + ctx->children[i]->err);
     return MDT_OK;
 }
 
@@ -569,14 +708,15 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     mdt_ctx* ctx = new (std::nothrow) mdt_ctx();
     if (!ctx) return MDT_ENOMEM;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
+    DeviceGuard guard(device_id);
+    if (!guard.ok) { delete ctx; return MDT_ERUNTIME; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
     ctx->num_cu = prop.multiProcessorCount;
     ctx->grid = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256); // two 512-thread or one 1024-thread workgroup per CU (LDS-bound)
     if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = 2 * v; } // diagnostics: workgroups of the big geometry
     if (const char* c = getenv("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
-    if (hipMalloc((void**)&ctx->status, 2 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
+    if (hipMalloc((void**)&ctx->status, 4 * sizeof(int)) != hipSuccess || hipMemset(ctx->status, 0, 4 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
     // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
     const void* kerns[] = {(const void*)mdt_big::mdt_kernel<double>, (const void*)mdt_big::mdt_kernel<float>,
                            (const void*)mdt_small::mdt_kernel<double>, (const void*)mdt_small::mdt_kernel<float>,
@@ -609,7 +749,12 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
 
 int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (!ctx) return MDT_OK;
-    (void)hipSetDevice(ctx->device);
+    if (!ctx->children.empty()) {
+        for (mdt_ctx* c : ctx->children) (void)mdt_ctx_destroy(c);
+        delete ctx;
+        return MDT_OK;
+    }
+    DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->r2buf) (void)hipFree(ctx->r2buf);
     if (ctx->binbuf) (void)hipFree(ctx->binbuf);
@@ -626,11 +771,70 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->mom) (void)hipFree(ctx->mom);
+    if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
     delete ctx;
     return MDT_OK;
 }
 
 const char* mdt_last_error(const mdt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int mdt_ctx_create_multi(mdt_ctx** out, const int* device_ids, int ndev) {
+    if (!out) return MDT_EARG;
+    *out = nullptr;
+    if (!device_ids || ndev < 1) return MDT_EARG;
+    for (int i = 0; i < ndev; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ids[i] == device_ids[j]) return MDT_EARG; // one block per GPU
+    mdt_ctx* ctx = new (std::nothrow) mdt_ctx();
+    if (!ctx) return MDT_ENOMEM;
+    ctx->device = device_ids[0];
+    for (int i = 0; i < ndev; ++i) {
+        mdt_ctx* c = nullptr;
+        const int rc = mdt_ctx_create(&c, device_ids[i]);
+        if (rc != MDT_OK) {
+            for (mdt_ctx* d : ctx->children) (void)mdt_ctx_destroy(d);
+            delete ctx;
+            return rc;
+        }
+        ctx->children.push_back(c);
+    }
+    // peer access for blocks that live on another GPU of the node (ignored where it is already on or unavailable:
+    // hipMemcpyPeer works either way)
+    for (int i = 0; i < ndev; ++i) {
+        DeviceGuard g(device_ids[i]);
+        for (int j = 0; j < ndev; ++j) {
+            int can = 0;
+            if (i != j && hipDeviceCanAccessPeer(&can, device_ids[i], device_ids[j]) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(device_ids[j], 0);
+        }
+        (void)hipGetLastError();
+    }
+    *out = ctx;
+    return MDT_OK;
+}
+
+int mdt_ctx_status(mdt_ctx* ctx, int32_t* flags, int32_t clear) {
+    if (!ctx || !flags) return MDT_EARG;
+    *flags = 0;
+    if (!ctx->children.empty()) {
+        for (mdt_ctx* c : ctx->children) {
+            int32_t f = 0;
+            const int rc = mdt_ctx_status(c, &f, clear);
+            if (rc) return fail(ctx, rc, c->err);
+            *flags |= f;
+        }
+        return MDT_OK;
+    }
+    MDT_ON_DEVICE(ctx);
+    int st[3] = {0, 0, 0};
+    if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    HIP_TRY(hipMemcpy(st, ctx->status, sizeof(st), hipMemcpyDeviceToHost));
+    *flags = st[0] | st[2];
+    if (clear && *flags) {
+        st[0] = 0; st[2] = 0;
+        HIP_TRY(hipMemcpy(ctx->status, st, sizeof(st), hipMemcpyHostToDevice));
+    }
+    return MDT_OK;
+}
 
 int mdt_ess_rhat(mdt_ctx* ctx, const mdt_args* a, const void* x, void* ess_out, void* rhat_out) {
     if (!ctx) return MDT_EARG;
@@ -723,6 +927,7 @@ int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out)
 
 int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out) {
     if (!ctx) return MDT_EARG;
+    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     if (!a) return fail(ctx, MDT_EARG, "args is NULL");
     if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
     if (a->kind != MDT_KIND_MEDIAN && a->kind != MDT_KIND_QUANTILE)
@@ -731,7 +936,7 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
     if (P <= 0) return run(ctx, a, x, Req());
     const double p = (a->kind == MDT_KIND_MEDIAN) ? 0.5 : a->tail_prob;
     const size_t ts = tsize(a->dtype);
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     if (P > ctx->mq_cap) {
         if (ctx->ess_tmp) (void)hipFree(ctx->ess_tmp);
@@ -783,6 +988,7 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
 
 int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void* x_dcp) {
     if (!ctx) return MDT_EARG;
+    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     if (!a || !x_dpc || !x_dcp) return fail(ctx, MDT_EARG, "NULL pointer");
     if (a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "mdt_layout_from_dpc works on device buffers");
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
@@ -791,7 +997,7 @@ int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void
     const long long runs = a->chains * a->params;
     if (runs == 0 || a->draws == 0) return MDT_OK;
     if (runs > 2147483647LL) return fail(ctx, MDT_EUNSUPPORTED, "chains*params too large");
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     if (a->dtype == MDT_F64)
         hipLaunchKernelGGL(permute_dpc_kernel<double>, dim3((unsigned)runs), dim3(256), 0, st, (const double*)x_dpc, (double*)x_dcp,
@@ -845,13 +1051,14 @@ static int diag_args_ok(mdt_ctx* ctx, const mdt_args* a) {
 
 int mdt_bfmi(mdt_ctx* ctx, const mdt_args* a, const void* energy, void* bfmi_out) {
     if (!ctx) return MDT_EARG;
+    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     int rc = diag_args_ok(ctx, a);
     if (rc) return rc;
     const long long ncol = a->chains * a->params;
     if (ncol == 0) return MDT_OK;
     if (!energy || !bfmi_out) return fail(ctx, MDT_EARG, "NULL pointer");
     if (a->draws == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     const size_t ob = (size_t)ncol * tsize(a->dtype);
     void* od = bfmi_out;
@@ -867,6 +1074,7 @@ int mdt_bfmi(mdt_ctx* ctx, const mdt_args* a, const void* energy, void* bfmi_out
 
 int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha, double* psrf, double* psrfci) {
     if (!ctx) return MDT_EARG;
+    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     int rc = diag_args_ok(ctx, a);
     if (rc) return rc;
     const long long D = a->draws, C = a->chains, P = a->params;
@@ -874,14 +1082,16 @@ int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha,
     if (P == 0) return MDT_OK;
     if (!x || !psrf || !psrfci) return fail(ctx, MDT_EARG, "NULL pointer");
     if (D == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     double* od0 = psrf; double* od1 = psrfci;
     if (a->location == MDT_HOST) {
         if ((rc = stage_out_bytes(ctx, (size_t)P * 16))) return rc;
         od0 = (double*)ctx->stage_out; od1 = od0 + P;
     }
-    HIP_TRY(hipMemsetAsync(ctx->status, 0, 2 * sizeof(int), st));
+    if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    hipLaunchKernelGGL(status_begin_kernel, dim3(1), dim3(64), 0, st, ctx->status);
+    ctx->last_stream = st; ctx->used = true;
     if ((rc = column_moments(ctx, a, x, C * P, nullptr))) return rc;
     double zq = 0.0; // standard normal quantile of 1 - alpha/2 (a start value only): Newton on erfc
     {
@@ -907,7 +1117,10 @@ int mdt_gelmandiag(mdt_ctx* ctx, const mdt_args* a, const void* x, double alpha,
         int status = 0;
         HIP_TRY(hipMemcpyAsync(&status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (status & 4) return fail(ctx, MDT_EARG, "FDist: the condition nu2 > zero(nu2) is not satisfied"); // Distributions.FDist
+        if (status & 4) {
+            HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(int), st));
+            return fail(ctx, MDT_EARG, "FDist: the condition nu2 > zero(nu2) is not satisfied"); // Distributions.FDist
+        }
     }
     return MDT_OK;
 }
@@ -920,9 +1133,10 @@ int mdt_debug_beta(double a, double b, double v, int32_t inverse, double* out) {
 
 int mdt_debug_phase_cycles(mdt_ctx* ctx, uint64_t* out16, int32_t reset) {
     if (!ctx || !out16) return MDT_EARG;
+    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     for (int i = 0; i < 16; ++i) out16[i] = 0;
     if (!ctx->prof) return fail(ctx, MDT_EUNSUPPORTED, "phase counters are off (create the context with MDT_PROF=1 in the environment)");
-    HIP_TRY(hipSetDevice(ctx->device));
+    MDT_ON_DEVICE(ctx);
     HIP_TRY(hipDeviceSynchronize());
     const size_t cnt = (size_t)ctx->grid * 2 * 16; // (the tiny geometry runs 2 * grid workgroups)
     unsigned long long* h = (unsigned long long*)malloc(cnt * sizeof(unsigned long long));

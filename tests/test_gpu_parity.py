@@ -378,19 +378,39 @@ def test_estimators_from_host_memory(pkg):
 
 
 def test_mcmcchains_storage_order(pkg):
-    """(iterations, parameters, chains) input -- MCMCChains storage -- through the device-side permutation"""
+    """(iterations, parameters, chains) input -- MCMCChains storage -- read IN PLACE through chain_stride /
+    param_stride (no permuted copy), and through the device-side permutation helper: bit-equal to the dense call"""
     import torch
     rng = np.random.default_rng(9)
     for dt in (np.float64, np.float32):
-        x = rng.standard_normal((300, 4, 7)).astype(dt)            # (draws, chains, params)
-        t = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (0, 2, 1)))).cuda()  # (draws, params, chains)
-        v = pkg.from_mcmcchains_layout(t)
-        assert v.shape == (300, 4, 7)
-        assert np.array_equal(v.cpu().numpy(), x)
-        assert v.permute(2, 1, 0).is_contiguous()                  # the zero-copy layout of the engine
-        a = pkg.ess_rhat(v)
-        b = pkg.ess_rhat(dev(x))
-        assert np.array_equal(host(a.ess), host(b.ess)) and np.array_equal(host(a.rhat), host(b.rhat))
+        for shape in ((300, 4, 7), (5000, 4, 9)):                 # rank variants 0 (small slices) and 2 (two-level)
+            x = (ar1(0.6, *shape, rng) + 0.1 * rng.standard_normal(shape)).astype(dt)   # (draws, chains, params)
+            # Julia's column-major (iterations, parameters, chains) = C-order (chains, parameters, iterations)
+            store = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 2, 0)))).cuda()
+            view = store.permute(2, 0, 1)                         # logical (draws, chains, params); strides (1, D*P, D)
+            assert view.shape == shape and view.stride() == (1, shape[0] * shape[2], shape[0])
+            assert np.array_equal(view.cpu().numpy(), x)
+            before = torch.cuda.memory_allocated()
+            a = pkg.ess_rhat(view)
+            bt = pkg.bulk_tail(view)
+            nested = pkg.rhat_nested(view, [1, 1, 2, 2])
+            m = pkg.mcse(view)
+            b = pkg.ess_rhat(dev(x))
+            assert np.array_equal(host(a.ess), host(b.ess)) and np.array_equal(host(a.rhat), host(b.rhat))
+            for u, w in zip(bt, pkg.bulk_tail(dev(x))):
+                assert np.array_equal(host(u), host(w), equal_nan=True)
+            assert np.array_equal(host(nested), host(pkg.rhat_nested(dev(x), [1, 1, 2, 2])))
+            assert np.array_equal(host(m), host(pkg.mcse(dev(x))))
+            for kind in ("basic", "tail", np.median):
+                assert np.array_equal(host(pkg.ess(view, kind=kind)), host(pkg.ess(dev(x), kind=kind)))
+            # nothing of the size of x was allocated on the way (outputs only)
+            assert torch.cuda.memory_allocated() - before < x.nbytes // 4
+            # the out-of-place helper still works
+            t = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (0, 2, 1)))).cuda()  # (draws, params, chains) C-order input
+            v = pkg.from_mcmcchains_layout(t)
+            assert v.shape == shape and np.array_equal(v.cpu().numpy(), x) and v.permute(2, 1, 0).is_contiguous()
+            c = pkg.ess_rhat(v)
+            assert np.array_equal(host(c.ess), host(b.ess)) and np.array_equal(host(c.rhat), host(b.rhat))
 
 
 def test_fewer_draws_than_splits(pkg):
@@ -746,3 +766,228 @@ def test_fold_merge_matches_general_ranking(pkg, monkeypatch, dtype):
         want = co.bulk_tail(x)
         for a, b, nm in zip(outs["1"], want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
             assert_close(a, b, RTOL64 if dtype == np.float64 else 1e-6, f"{nm} {D}x{C} {np.dtype(dtype).name}")
+
+
+def test_rhat_many_chains(pkg):
+    """more split chains than the LDS moment tables hold (chains*split_chains > 256): the reference's own suite runs
+    rhat_nested on 10 draws x 2048 chains x 32 params in 8 and 16 superchains and asks 1 < R < 1.001
+    (test/rhat_nested.jl:157-169); rhat of every kind takes the same route; ESS there is refused, not approximated"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(2048)
+    x = rng.standard_normal((10, 2048, 32))
+    xd = dev(x)
+    for nsuper in (8, 16):
+        ids = np.repeat(np.arange(1, nsuper + 1), 2048 // nsuper)
+        inds = np.arange(2048, dtype=np.int32).reshape(2048 // nsuper, nsuper, order="F")
+        for kind in KINDS:
+            for s in (1, 2):
+                got = host(pkg.rhat_nested(xd, ids, kind=kind, split_chains=s))
+                assert_close(got, co.rhat_nested(x, inds, kind=kind, split_chains=s), RTOL64, f"nested {nsuper} {kind} {s}")
+        R = host(pkg.rhat_nested(xd, ids))
+        assert R.min() > 1 and R.max() < 1.001
+    for kind in KINDS:
+        for s in (1, 2, 3):
+            got = host(pkg.rhat(xd, kind=kind, split_chains=s))
+            assert_close(got, co.ess_rhat(x, kind=kind, split_chains=s)[1], RTOL64, f"rhat {kind} {s}")
+    # longer chains, fewer of them, Float32, one superchain layout that is not contiguous
+    y = (ar1(0.5, 300, 320, 5, rng) + 0.05 * rng.standard_normal((1, 320, 1))).astype(np.float32)
+    ids = np.tile(np.arange(4), 80)
+    inds = np.stack([np.nonzero(ids == k)[0] for k in range(4)], axis=1).astype(np.int32)
+    for kind in KINDS:
+        assert_close(host(pkg.rhat_nested(dev(y), ids, kind=kind)), co.rhat_nested(y, inds, kind=kind), 1e-6, f"nested f32 {kind}")
+        assert_close(host(pkg.rhat(dev(y), kind=kind)), co.ess_rhat(y, kind=kind)[1], 1e-6, f"rhat f32 {kind}")
+    with pytest.raises(NotImplementedError):
+        pkg.ess(xd)
+    with pytest.raises(NotImplementedError):
+        pkg.mcse(xd)
+
+
+def test_rhat_nested_permutation_invariance_bitwise(pkg):
+    """R == R_perm under a simultaneous permutation of chains and superchain ids, with == as the reference's suite
+    has it (test/rhat_nested.jl:113-130): the sums over the chains of a superchain run in sorted order"""
+    rng = np.random.default_rng(77)
+    for nsuper in (8, 16):
+        for per in (2, 4):
+            for s in (1, 2):
+                nch = nsuper * per
+                x = rng.standard_normal((100, nch, 10))
+                ids = np.repeat(np.arange(1, nsuper + 1), per)
+                perm = rng.permutation(nch)
+                for kind in KINDS:
+                    R = host(pkg.rhat_nested(dev(x), ids, kind=kind, split_chains=s))
+                    Rp = host(pkg.rhat_nested(dev(x[:, perm, :]), ids[perm], kind=kind, split_chains=s))
+                    assert np.array_equal(R, Rp), (nsuper, per, s, kind)
+    # many chains: the one-thread-per-chain route
+    x = rng.standard_normal((10, 2048, 8))
+    ids = np.repeat(np.arange(1, 9), 256)
+    perm = rng.permutation(2048)
+    for kind in KINDS:
+        assert np.array_equal(host(pkg.rhat_nested(dev(x), ids, kind=kind)), host(pkg.rhat_nested(dev(x[:, perm, :]), ids[perm], kind=kind)))
+    # label values and types do not matter (:102-111)
+    x = rng.standard_normal((100, 4, 10))
+    for kind in KINDS:
+        R = host(pkg.rhat_nested(dev(x), [1, 1, 2, 2], kind=kind))
+        assert np.array_equal(R, host(pkg.rhat_nested(dev(x), [42, 42, 99, 99], kind=kind)))
+        assert np.array_equal(R, host(pkg.rhat_nested(dev(x), ["a", "a", "b", "b"], kind=kind)))
+
+
+def test_missing_and_param_axes_on_device(pkg):
+    """Union{Missing,T} input (param-wise missing, test/ess_rhat.jl:115-132) as numpy masked arrays, and parameter
+    axes of any rank: slices of a 4-d array reproduce the bits of the whole call (:167-204)"""
+    import warnings
+    rng = np.random.default_rng(31)
+    for kind in KINDS:
+        x = np.ma.MaskedArray(rng.standard_normal((1000, 4, 3)), mask=False)
+        x[0, 0, 0] = np.ma.masked
+        S1 = pkg.ess(x, kind="bulk" if kind == "rank" else kind)
+        R1 = pkg.rhat(x, kind=kind)
+        S2, R2 = pkg.ess_rhat(x, kind=kind)
+        for o in (S1, R1, S2, R2):
+            assert np.ma.getmaskarray(o)[0] and not np.ma.getmaskarray(o)[1:].any()
+            assert np.all(np.isfinite(np.asarray(o[1:], dtype=np.float64)))
+    x = rng.standard_normal((1000, 4, 10, 3))
+    import torch
+    xt = torch.from_numpy(x).cuda()
+    for kind in KINDS:
+        for s in (1, 2):
+            R1 = host(pkg.rhat(xt, kind=kind, split_chains=s))
+            assert R1.shape == (10, 3)
+            for i in range(3):
+                assert np.array_equal(host(pkg.rhat(xt[:, :, :, i], kind=kind, split_chains=s)), R1[:, i])
+                for j in (0, 4, 9):
+                    assert pkg.rhat(xt[:, :, j, i], kind=kind, split_chains=s) == R1[j, i]
+            for method in (pkg.AutocovMethod(), pkg.BDAAutocovMethod()):
+                for ml in (100, 10):
+                    ke = "bulk" if kind == "rank" else kind
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        S1 = host(pkg.ess(xt, kind=ke, split_chains=s, autocov_method=method, maxlag=ml))
+                        S2, R2 = pkg.ess_rhat(xt, kind=kind, split_chains=s, autocov_method=method, maxlag=ml)
+                    assert np.array_equal(S1, host(S2)) and np.array_equal(R1, host(R2))
+                    for i in range(3):
+                        r = pkg.ess_rhat(xt[:, :, :, i], kind=kind, split_chains=s, autocov_method=method, maxlag=ml)
+                        assert np.array_equal(host(r.ess), S1[:, i]) and np.array_equal(host(r.rhat), R1[:, i])
+                        r = pkg.ess_rhat(xt[:, :, 7, i], kind=kind, split_chains=s, autocov_method=method, maxlag=ml)
+                        assert r.ess == S1[7, i] and r.rhat == R1[7, i]
+
+
+def test_async_requests_keep_their_flags(pkg):
+    """sync = False cannot raise: a NaN under a quantile (the reference throws ArgumentError, Statistics.quantile at
+    src/ess_rhat.jl:655) stays as a sticky flag on the context until mdt_ctx_status reports it -- through any number
+    of later launches -- and the affected output is NaN"""
+    import torch
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2000, 4, 50))
+    clean = dev(x)
+    x[17, 1, 5] = np.nan
+    bad = dev(x)
+    assert pkg.status() == 0
+    with pytest.raises(pkg.ArgumentError):
+        pkg.bulk_tail(bad)                                  # synchronous: raised here, nothing left behind
+    assert pkg.status() == 0
+    out = pkg.bulk_tail(bad, sync=False)
+    for _ in range(70):                                      # more launches than parameter-ring slots, none synchronising
+        pkg.bulk_tail(clean, sync=False)
+    torch.cuda.synchronize()
+    assert np.isnan(host(out[1])[5]) and np.isfinite(host(out[1])[[4, 6]]).all()
+    assert pkg.status(clear=False) == pkg.FLAG_NAN_QUANTILE
+    assert pkg.status() == pkg.FLAG_NAN_QUANTILE             # ... and cleared by this call
+    assert pkg.status() == 0
+
+
+def test_out_buffers_are_validated(pkg):
+    import torch
+    x = dev(np.random.default_rng(3).standard_normal((500, 4, 6)))
+    good = [torch.empty(6, dtype=torch.float64, device="cuda") for _ in range(4)]
+    assert pkg.bulk_tail(x, out=good) is good
+    ref = pkg.bulk_tail(x)
+    for a, b in zip(good, ref):
+        assert torch.equal(a, b)
+    for bad in (good[:3], [torch.empty(6, dtype=torch.float32, device="cuda")] * 4, [torch.empty(5, dtype=torch.float64, device="cuda")] * 4,
+                [torch.empty(6, dtype=torch.float64)] * 4, [torch.empty(12, dtype=torch.float64, device="cuda")[::2]] * 4,
+                [np.empty(6)] * 4):
+        with pytest.raises((pkg.ArgumentError, pkg.DimensionMismatch)):
+            pkg.bulk_tail(x, out=bad)
+
+
+def test_multi_gpu_context_and_current_device(pkg):
+    """mdt_ctx_create_multi over every GPU of the box (one on the test box: the path still runs -- blocks, threads,
+    gather): bit-equal to the single-context result, from device and from host memory; and no call moves the calling
+    thread's current device"""
+    import torch
+    ndev = torch.cuda.device_count()
+    devices = list(range(ndev))
+    rng = np.random.default_rng(12)
+    x = ar1(0.4, 1200, 4, 37, rng)
+    xd = dev(x)
+    cur = torch.cuda.current_device()
+    ref = [host(o) for o in pkg.bulk_tail(xd)]
+    for src in (xd, x):
+        got = [host(o) for o in pkg.bulk_tail(src, devices=devices)]
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b, equal_nan=True)
+    ids = [1, 1, 2, 2]
+    assert np.array_equal(host(pkg.rhat_nested(xd, ids, devices=devices)), host(pkg.rhat_nested(xd, ids)))
+    assert np.array_equal(host(pkg.mcse(xd, devices=devices)), host(pkg.mcse(xd)))
+    r = pkg.ess_rhat(x, devices=devices)
+    r0 = pkg.ess_rhat(xd)
+    assert np.array_equal(host(r.ess), host(r0.ess)) and np.array_equal(host(r.rhat), host(r0.rhat))
+    assert pkg.status(devices=devices) == 0
+    assert torch.cuda.current_device() == cur
+    if ndev > 1:   # a tensor on the last GPU: the call must leave the current device alone
+        with torch.cuda.device(0):
+            xl = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (2, 1, 0)))).to(f"cuda:{ndev - 1}").permute(2, 1, 0)
+            got = [host(o) for o in pkg.bulk_tail(xl)]
+            assert torch.cuda.current_device() == 0
+            for a, b in zip(got, ref):
+                assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_shard_size_config4_properties(pkg):
+    """BASELINE config 4's per-GPU shard: 10 000 draws x 4 chains x 125 000 params Float64 (40 GB resident)"""
+    _full_size_properties(pkg, 10000, 4, 125000, 24)
+
+
+def test_shard_size_config5_f32_nested_and_mcse(pkg):
+    """BASELINE config 5's per-GPU shard: 10 000 draws x 16 chains (4 superchains) x 12 500 params Float32 (8 GB):
+    mcse(kind = mean) and rhat_nested(kind = rank) -- sub-batch bits, exact invariance under x -> 2x, the oracle on a sample"""
+    import torch
+    from oracle import c_oracle as co
+    D, C, P = 10000, 16, 12500
+    g = torch.Generator(device="cuda").manual_seed(55)
+    base = 0.2 * torch.randn(P, 4, 1, generator=g, device="cuda", dtype=torch.float32)
+    x = torch.randn(P, C, D, generator=g, device="cuda", dtype=torch.float32)
+    # AR(1) by blocks of 100 draws (the recipe of bench.synth), phi = 0.6, superchain-shared offsets (test/rhat_nested.jl:8-21)
+    phi = 0.6
+    idx = torch.arange(100, device="cuda", dtype=torch.float32)
+    dlt = idx[:, None] - idx[None, :]
+    L = torch.where(dlt >= 0, phi ** dlt.clamp(min=0), torch.zeros((), device="cuda"))
+    carry = phi ** (idx + 1.0)
+    half = P // 2
+    y = (x[half:] * (1 - phi * phi) ** 0.5).reshape(-1, D // 100, 100) @ L.T
+    prev = torch.zeros(y.shape[0], 1, device="cuda")
+    for b in range(D // 100):
+        y[:, b, :] += prev * carry
+        prev = y[:, b, -1:].clone()
+    x[half:] = y.reshape(P - half, C, D)
+    del y
+    x += base.repeat_interleave(4, dim=1)
+    xv = x.permute(2, 1, 0)
+    ids = np.repeat(np.arange(1, 5), 4)
+    inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
+    full = [host(pkg.mcse(xv)), host(pkg.rhat_nested(xv, ids, kind="rank"))]
+    assert all(f.shape == (P,) and np.all(np.isfinite(f)) for f in full)
+    sel = torch.arange(5, P, P // 61, device="cuda")
+    sub_x = x[sel].contiguous().permute(2, 1, 0)
+    sub = [host(pkg.mcse(sub_x)), host(pkg.rhat_nested(sub_x, ids, kind="rank"))]
+    for f, s_ in zip(full, sub):
+        assert np.array_equal(f[sel.cpu().numpy()], s_)
+    x2 = xv * 2.0
+    assert np.array_equal(host(pkg.rhat_nested(x2, ids, kind="rank")), full[1])      # ranks and folds do not move
+    assert_close(host(pkg.mcse(x2)), 2.0 * full[0], 1e-6)
+    del x2
+    pick = np.linspace(0, P - 1, 6).astype(np.int64)
+    xs = x[torch.as_tensor(pick, device="cuda")].permute(2, 1, 0).cpu().numpy()
+    assert_close(full[0][pick], co.mcse_mean(xs), 1e-6, "cfg5 mcse")
+    assert_close(full[1][pick], co.rhat_nested(xs, inds, kind="rank"), 1e-6, "cfg5 nested")
+    assert np.all(full[1] >= 1.0) and np.all(full[1] < 1.3)  # sqrt(1 + B / W) with superchain offsets of sd 0.2
