@@ -31,6 +31,121 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def synth_cfg5(draws, chains, params, device, seed):
+    """BASELINE config 5 data: (params, chains, draws) float32; chains grouped in superchains of 4 that share their
+    initial value (the ar1_superchains recipe of test/rhat_nested.jl:8-21: x[1] = init, x[t] = phi x[t-1] + eps[t]);
+    half the parameters phi = 0 (IID after the first draw), half phi = 0.6, unit stationary variance."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    init = torch.randn(params, chains // 4, 1, generator=g, device=device, dtype=torch.float32)
+    x = torch.randn(params, chains, draws, generator=g, device=device, dtype=torch.float32)
+    x[:, :, :1] = init.repeat_interleave(4, dim=1)  # the first "innovation" is the shared initial value
+    phi, B = 0.6, 100
+    idx = torch.arange(B, device=device, dtype=torch.float32)
+    dlt = idx[:, None] - idx[None, :]
+    L = torch.where(dlt >= 0, phi ** dlt.clamp(min=0), torch.zeros((), device=device))
+    carry = phi ** (idx + 1.0)
+    half = params // 2
+    e = x[half:]
+    e[:, :, 1:] *= (1 - phi * phi) ** 0.5
+    y = e.reshape(-1, draws // B, B) @ L.T
+    prev = torch.zeros(y.shape[0], 1, device=device)
+    for b in range(draws // B):
+        y[:, b, :] += prev * carry
+        prev = y[:, b, -1:].clone()
+    x[half:] = y.reshape(params - half, chains, draws)
+    return x
+
+
+def timed_ms(fn, steps, warmup):
+    """average HIP-event duration of fn() on the current stream"""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / steps
+
+
+def max_rel_err(got, want):
+    err = 0.0
+    for a, b in zip(got, want):
+        m = np.isfinite(b)
+        if m.any():
+            err = max(err, float(np.max(np.abs(np.asarray(a, dtype=np.float64)[m] - b[m]) / np.abs(b[m]))))
+    return err
+
+
+def other_configs(pkg, device, steps, warmup):
+    """BASELINE configs 3 and 5 (per-GPU shard) measured in the same run: time per call, param-series/s, the
+    HBM-roofline fraction on algorithmic bytes, and the oracle on a few parameters of the timed array."""
+    from oracle import c_oracle
+    out = {}
+    # ---- config 3: 100 000 draws x 8 chains x 1 000 params Float64, FFTAutocovMethod (the long-chain case)
+    D, C, P = 100_000, 8, 1_000
+    x_pcd = synth(D, C, P, device, seed=4321)
+    x = x_pcd.permute(2, 1, 0)
+    m = pkg.FFTAutocovMethod()
+    outs = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
+    ms = timed_ms(lambda: pkg.bulk_tail(x, autocov_method=m, sync=False, out=outs), steps, warmup)
+    flags = pkg.status()
+    pick = np.array([1, P // 2 + 3, P - 1])
+    xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
+    t1 = time.perf_counter()
+    want = c_oracle.bulk_tail(xs, autocov="fft")
+    cpu_t = time.perf_counter() - t1
+    b_alg = D * C * 8 + 4 * 8
+    out["config3"] = {
+        "workload": "ess_rhat bulk+tail, 100000 draws x 8 chains x 1000 params Float64, FFTAutocovMethod (BASELINE.json configs[2])",
+        "ms": ms, "param_series_per_s": P / (ms * 1e-3), "kernel": "mdt_big::mdt_kernel<double>",
+        "roofline": {"bound": "hbm", "achieved": P * b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_param": b_alg},
+        "parity_max_rel_err_vs_oracle": max_rel_err([o.cpu().numpy()[pick] for o in outs], want),
+        "parity_sample": f"{len(pick)} parameters against oracle/mdt_oracle.c with its real FFT",
+        "cpu_port_param_series_per_s_1core": len(pick) / cpu_t, "status_flags": flags,
+    }
+    del x, x_pcd, outs
+    torch.cuda.empty_cache()
+    # ---- config 5, one GPU's shard: 10 000 draws x 16 chains (4 superchains) x 12 500 params Float32
+    D, C, P = 10_000, 16, 12_500
+    x_pcd = synth_cfg5(D, C, P, device, seed=55)
+    x = x_pcd.permute(2, 1, 0)
+    ids = np.repeat(np.arange(1, 5), 4)
+    res = {}
+
+    def step5():
+        res["mcse"] = pkg.mcse(x)
+        res["nested"] = pkg.rhat_nested(x, ids, kind="rank")
+    step5()
+    torch.cuda.synchronize()
+    t_m = timed_ms(lambda: pkg.mcse(x), steps, 1)
+    t_n = timed_ms(lambda: pkg.rhat_nested(x, ids, kind="rank"), steps, 1)
+    flags = pkg.status()
+    pick = np.array([0, 7, P // 2 + 1, P - 2])
+    xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
+    inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
+    want = [c_oracle.mcse_mean(xs), c_oracle.rhat_nested(xs, inds, kind="rank")]
+    got = [res["mcse"].cpu().numpy()[pick], res["nested"].cpu().numpy()[pick]]
+    b_alg = D * C * 4 + 4  # per call: read the slice once, one output value
+    ms = t_m + t_n
+    out["config5_shard"] = {
+        "workload": "mcse(kind=mean) + rhat_nested(kind=rank), 10000 draws x 16 chains (4 superchains) x 12500 params Float32: "
+                    "one GPU's shard of BASELINE.json configs[4] (100000 params over 8 GPUs); two calls (synchronous, as the reference's API is)",
+        "ms": ms, "ms_mcse_mean": t_m, "ms_rhat_nested_rank": t_n, "param_series_per_s": P / (ms * 1e-3),
+        "kernel": "mdt_small::mdt_kernel<float>",
+        "roofline": {"bound": "hbm", "achieved": 2 * P * b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": 2 * P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_param": 2 * b_alg,
+                     "note": "two separate calls: the slice is counted twice (SURVEY.md 8d)"},
+        "parity_max_rel_err_vs_oracle": max_rel_err(got, want),
+        "parity_sample": f"{len(pick)} parameters against oracle/mdt_oracle.c (Float32 input, Float64 internal comparator)",
+        "status_flags": flags,
+    }
+    return out
+
+
 def synth(draws, chains, params, device, seed):
     """(params, chains, draws) float64 tensor (draws fastest): half IID, half AR(1)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -72,6 +187,8 @@ def main():
     ap.add_argument("--params", type=int, default=10_000, help="parameters per GPU")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the BASELINE configs 3 and 5 that the N = 1 line reports beside the headline")
     ap.add_argument("--streams", type=int, default=1,
                     help="pipelining experiment (DESIGN.md §5): round-robin the steps over this many HIP streams, each with "
                          "its own context, so that the tail of one persistent launch overlaps the head of the next; the "
@@ -144,6 +261,10 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the stream the kernel runs on
+    # the timed requests were asynchronous: what they could not raise is on the context (mdt_ctx_status)
+    status_flags = pkg.status() if not streams else 0
+    if status_flags:
+        raise SystemExit(f"bench.py: the timed launches raised condition flags {status_flags} (see include/mdt_hip.h MDT_FLAG_*)")
     if streams:  # overlapping launches: the per-step figure is the wall time; per-launch durations are in rocprofv3
         kernel_ms = elapsed / args.steps * 1e3
         outs = outs_s[0]
@@ -177,7 +298,7 @@ def main():
                             + "; half IID N(0,1), half AR(1) phi in (-0.3,0.3,0.7,0.9)",
                 "draws": D, "chains": C, "params_per_gpu": P, "autocov_method": type(method).__name__,
                 "split_chains": 2, "maxlag": 250, "tail_prob": 0.1, "sharding": f"params axis x{world}",
-                "streams": args.streams,
+                "streams": args.streams, "status_flags_after_timed_loop": status_flags,
             },
             "roofline": {
                 "bound": "hbm",
@@ -186,7 +307,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "kernel": "mdt_kernel<double>",
+                "traffic_source": None,
+                "kernel": "mdt_small::mdt_kernel<double>",
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_param": b_alg,
             },
@@ -199,6 +321,8 @@ def main():
                     tj = json.load(f)
                 if tj.get("draws") == D and tj.get("chains") == C and tj.get("params") == P:
                     res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                    res["roofline"]["traffic_source"] = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                         "workload, calibrated on a copy kernel of known size (not measured in this run)")
             except Exception:
                 pass
 
@@ -234,21 +358,30 @@ def main():
         }
         res["parity_max_rel_err_vs_oracle"] = err
         res["speedup_vs_cpu_1core"] = res["value"] / res["cpu_baseline"]["value"]
-        # the same oracle on all host cores (parameters are independent; ctypes releases the GIL)
+        # the same oracle on all host cores: one contiguous block of parameters per thread (parameters are independent;
+        # ctypes releases the GIL), at least 64 parameters per thread where the array has that many
         try:
             from concurrent.futures import ThreadPoolExecutor
             ncore = len(os.sched_getaffinity(0))
             if ncore > 1:
-                chunks = [c for c in np.array_split(np.arange(ns), ncore * 2) if len(c)]
-                parts = [np.ascontiguousarray(xs[:, :, c]) for c in chunks]
+                nall = int(min(P, max(64 * ncore, ns)))
+                sel_all = np.linspace(0, P - 1, nall).astype(np.int64)
+                xa = x_pcd[torch.as_tensor(sel_all, device=device)].permute(2, 1, 0).cpu().numpy()
+                parts = [np.ascontiguousarray(xa[:, :, c]) for c in np.array_split(np.arange(nall), ncore) if len(c)]
                 t1 = time.perf_counter()
                 with ThreadPoolExecutor(ncore) as ex:
                     list(ex.map(lambda a: c_oracle.bulk_tail(a, autocov=args.autocov), parts))
                 tall = time.perf_counter() - t1
-                res["cpu_baseline_all_cores"] = {"value": ns / tall, "unit": "param-series/s", "cores": ncore, "kind": "port",
-                                                 "sample": f"the same {ns} parameters split over {ncore} threads, {tall:.1f} s"}
+                res["cpu_baseline_all_cores"] = {"value": nall / tall, "unit": "param-series/s", "cores": ncore, "kind": "port",
+                                                 "sample": f"{nall} parameters of the same array, one block of {nall // ncore}-{-(-nall // ncore)} per thread "
+                                                           f"over {ncore} threads, {tall:.1f} s"}
+                del xa, parts
         except Exception as e:  # the single-core figure above is the contractual one
             res["cpu_baseline_all_cores"] = {"error": str(e)}
+    if rank == 0 and world == 1 and not args.no_other_configs and (D, C, P) == (10000, 4, 10000) and not streams:
+        del x, x_pcd
+        torch.cuda.empty_cache()
+        res["other_configs"] = other_configs(pkg, device, steps=5, warmup=1)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

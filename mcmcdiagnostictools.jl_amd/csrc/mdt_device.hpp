@@ -69,7 +69,8 @@ constexpr int OFF_PROFT = OFF_SCAL + 24 * 8;              // int64 last profilin
 constexpr int OFF_TPOS = OFF_PROFT + 8;                   // uint32 tpos[8]
 constexpr int OFF_INTS = OFF_TPOS + 8 * 4;                // int ints[24]
 constexpr int OFF_WTOT = OFF_INTS + 24 * 4;               // uint32 wtot[16]
-constexpr int OFF_RLO = OFF_WTOT + 16 * 4;                // int rlo[MAXROUNDS]
+constexpr int OFF_ORK = OFF_WTOT + 16 * 4;                // uint32 orank[8]: doubled tied rank of every captured order statistic
+constexpr int OFF_RLO = OFF_ORK + 8 * 4;                  // int rlo[MAXROUNDS]
 constexpr int OFF_RHI = OFF_RLO + MAXROUNDS * 4;          // int rhi[MAXROUNDS]
 constexpr int OFF_RBASE = OFF_RHI + MAXROUNDS * 4;        // uint32 rbase[MAXROUNDS]
 constexpr int OFF_RCUR = OFF_RBASE + MAXROUNDS * 4;       // uint32 rcur[MAXROUNDS]: fill level of each round's segment
@@ -111,6 +112,8 @@ struct KP {
     long long cstride, pstride; // elements between chains / parameters of x (dense: D, D*C)
     int strided;                // x is not dense: every workgroup gathers its parameter into xcbuf first
     void* xcbuf;                // per-workgroup scratch for that, stride n_pad elements of T
+    unsigned long long* ibits;  // per-workgroup scratch, stride ibits_stride words: the tail-ESS indicator bits of every split chain, taken from the z-series
+    long long ibits_stride;
     long long D, C, P, n;       // draws, chains, params, n = D*C
     long long niter;            // D / s
     int s, rem, m;              // split_chains, D % s, m = C*s
@@ -217,7 +220,11 @@ struct SrcPlain {      // x itself
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); }
     __device__ __forceinline__ double operator()(long long e) const { return (double)xp[e]; }
     // element base + i with a wave-uniform base: scalar base register + 32-bit lane offset, no 64-bit address math
+#ifdef MDT_NT_X /* experiment: stream x past the caches */
+    __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)__builtin_nontemporal_load((xp + base) + i); }
+#else
     __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)(xp + base)[i]; }
+#endif
 };
 template <typename T>
 struct SrcFold {       // |x - median|, evaluated in T like the reference (src/utils.jl:155)
@@ -480,10 +487,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // the chains of this parameter are gathered -- each a coalesced stream -- into the workgroup's own dense
             // scratch slice, which stays cache-resident for the passes that follow
             T* xc = (T*)kp.xcbuf + (long long)blockIdx.x * kp.n_pad;
-            const unsigned uD = (unsigned)D;
-            for (unsigned e = (unsigned)tid; e < (unsigned)n; e += NT) {
-                const unsigned c = e / uD, d = e - c * uD;
-                xc[e] = xp[(long long)c * kp.cstride + d];
+            constexpr int GU = 10; // loads in flight per thread
+            if (D >= NT) {
+                for (long long c = 0; c < kp.C; ++c) {
+                    const MDT_GA T* src = (const MDT_GA T*)xp + c * kp.cstride;
+                    MDT_GA T* dst = (MDT_GA T*)xc + c * D;
+                    for (long long d0 = 0; d0 < D; d0 += (long long)NT * GU) {
+                        T v[GU];
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) { const long long d = d0 + u * NT + tid; v[u] = src[d < D ? d : D - 1]; }
+#pragma unroll
+                        for (int u = 0; u < GU; ++u) { const long long d = d0 + u * NT + tid; if (d < D) dst[d] = v[u]; }
+                    }
+                }
+            } else { // many short chains: one pass over the pooled index
+                const unsigned uD = (unsigned)D;
+                for (unsigned e = (unsigned)tid; e < (unsigned)n; e += NT) {
+                    const unsigned c = e / uD, d = e - c * uD;
+                    xc[e] = xp[(long long)c * kp.cstride + d];
+                }
             }
             __syncthreads();
             xp = xc;
@@ -679,6 +701,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 qhiT = qq[1];
             }
         }
+        // tail-ESS indicators from the z-series (series_z_phase, gbits): x <= q  <=>  x <= (largest order statistic <= q)
+        // <=> z <= its score.  q lies between the two captured neighbours a <= b: that statistic is a (q < b) or b (q == b);
+        // anything else (rounding past b, NaN) leaves the decision to the comparisons on x themselves
+        double zq[2] = {0.0, 0.0};
+        bool zq_ok = need_q && !has_nan && kp.need_et && kp.est == 0;
+        if (zq_ok) {
+            const int t0 = need_med ? 2 : 0;
+            const unsigned* orank = (const unsigned*)(smem + OFF_ORK);
+            const T qq2[2] = {qloT, qhiT};
+            for (int i = 0; i < 2; ++i) {
+                const T a = (T)ostat[t0 + 2 * i], b = (T)ostat[t0 + 2 * i + 1];
+                const int pick = (qq2[i] >= a && qq2[i] < b) ? 0 : ((qq2[i] == b) ? 1 : -1);
+                if (pick < 0) { zq_ok = false; break; }
+                const unsigned r2 = orank[t0 + 2 * i + pick];
+                int zero = 0;
+                asm volatile("" : "+v"(zero));
+                zq[i] = ztab[((r2 & 1u) ? r2 : (unsigned)(2 * n + 1) + (r2 >> 1)) + zero];
+            }
+            zq_ok = uni(zq_ok);
+        }
+        unsigned long long* gb = kp.ibits + (long long)blockIdx.x * kp.ibits_stride;
+        bool bits_done = false;
         __syncthreads();
         const SrcFold<T> VF{(const MDT_GA T*)xp, medT};
         auto rank_folded = [&](int nt, int out_req) {
@@ -743,7 +787,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_fft_phase(kp, YZ, smem);
             } else if (zfast || !acov) {
-                so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, acov, smem) : series_z_phase<false>(kp, zb, nullptr, acov, smem);
+                // (with the autocovariance every chain passes through LDS in time order: the indicator bits are taken there)
+                bits_done = zq_ok && acov && kp.ess_ok && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
+                unsigned long long* gq = bits_done ? gb : nullptr;
+                so = (rk == 2) ? series_z_phase<true>(kp, zb, (const unsigned short*)pbuf, acov, smem, gq, zq[0], zq[1])
+                               : series_z_phase<false>(kp, zb, nullptr, acov, smem, gq, zq[0], zq[1]);
                 if (acov) so.ess = fft_const_chain_nan(so.ess);
             } else {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
@@ -778,7 +826,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         if (kp.need_et && kp.ess_ok) {
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
             else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
-                et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem);
+                et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);
             else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem);
             MDT_PROF_MARK(PH_IND);
         }

@@ -81,6 +81,9 @@ struct mdt_ctx {
     // strided input: per-workgroup dense copy of the parameter being worked on
     void* xcbuf = nullptr;
     long long xc_elems = 0;
+    // tail-ESS indicator bits of every split chain (taken from the z-series), per workgroup
+    unsigned long long* ibits = nullptr;
+    long long ibits_stride = 0, ibits_cap = 0;
     // status words (flags of the launch, ticket, sticky flags) + nested chain indices
     int* status = nullptr;
     unsigned long long* prof = nullptr; // [2*grid*16] phase cycle counters when MDT_PROF is set
@@ -337,6 +340,14 @@ int ensure_scratch(mdt_ctx* ctx, long long n, long long wgs) {
         ctx->scratch_elems = need;
     }
     ctx->n_pad = n_pad; // the stride of this request: every workgroup owns [blockIdx * n_pad, +n_pad)
+    ctx->ibits_stride = n_pad / 32 + 256; // 2 indicators x (n / 64 + one word per split chain) words
+    if (wgs * ctx->ibits_stride > ctx->ibits_cap) {
+        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        if (ctx->ibits) (void)hipFree(ctx->ibits);
+        ctx->ibits = nullptr; ctx->ibits_cap = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->ibits, (size_t)(wgs * ctx->ibits_stride) * sizeof(unsigned long long)));
+        ctx->ibits_cap = wgs * ctx->ibits_stride;
+    }
     return MDT_OK;
 }
 
@@ -527,6 +538,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     memset(&kp, 0, sizeof(kp));
     kp.x = dx;
     kp.cstride = cs; kp.pstride = ps; kp.strided = strided ? 1 : 0; kp.xcbuf = ctx->xcbuf;
+    kp.ibits = ctx->ibits; kp.ibits_stride = getenv("MDT_NO_IBITS") ? 0 : ctx->ibits_stride; // (MDT_NO_IBITS: indicators from x itself; tests, A/B timing)
     kp.D = D; kp.C = C; kp.P = P; kp.n = n;
     kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
     kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est; kp.fft_lds = fft_lds ? 1 : 0;
@@ -772,6 +784,7 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->mom) (void)hipFree(ctx->mom);
     if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
+    if (ctx->ibits) (void)hipFree(ctx->ibits);
     delete ctx;
     return MDT_OK;
 }

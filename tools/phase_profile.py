@@ -28,7 +28,8 @@ NAMES = {0: "load x -> registers", 1: "rank x (tail)", 2: "series bulk (moments+
 
 
 NAMES_Q = {13: "  rank: partition pass", 14: "  rank: round load + local histogram", 15: "  rank: round prefix",
-           7: "  rank: round output (scores / tags)", 11: "  rank: round placement", 12: "  rank: round count (+ sorted copy)"}
+           7: "  rank: round output (scores / tags)", 11: "  rank: round placement", 12: "  rank: round scores: table lookup, back to partition order",
+           0: "  rank: round count loop (+ sorted value store)", 6: "  rank: round sorted tags (+ outputs)"}
 
 
 NAMES_F = {13: "  fold merge: tile boundaries", 14: "  fold merge: staging (loads, fold, LDS stores)", 15: "  fold merge: diagonal search + merge",
