@@ -127,6 +127,7 @@ struct KP {
     const unsigned int* tpos_arr; // mode 5: [P][2] zero-based sorted positions (l-1, u-1) per parameter; 0xFFFFFFFF: NaN
     int fft_lds;                // FFTAutocovMethod: 1 = run the in-LDS transform when it fits (MDT_FFT_LDS=1), 0 = lagged products
     int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
+    int winout;                 // 1: chains that do not fit the LDS take the windowed score layout (series_win_phase); 0: time-order scatter (MDT_WINOUT=0: tests, A/B timing)
     int fold_merge;             // 1: rank |x - median| by merging the sorted slice when the ranking of x left one (fold_merge_phase); 0: always the general ranking (MDT_FOLD_MERGE=0: tests, A/B timing)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
@@ -653,6 +654,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold) || kp.mode == 5;
         // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
         const bool seg_req = zfast && !fft_lds && kp.mode != 3;
+        // chains that cannot fit the LDS whatever maxlag is (so that rhat(x), which runs with maxlag = 1, and
+        // ess_rhat(x) decide alike and their R-hat stays the same bits): the ranking delivers the moments itself and,
+        // when an autocovariance follows, the windowed score layout of series_win_phase instead of a time-order scatter
+        const bool long_chain = kp.winout && kp.niter + 41 > SZ && !fft_lds && kp.mode != 3 && kp.m + 1 <= 64 &&
+                                kp.maxlag + 40 + MAXROUNDS <= PT_CAP / 4;
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
         if (need_rank_x) {
             if (kp.rank_variant == 2) {
@@ -660,7 +666,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                                   // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
                                   (est_ind || kp.mode == 5 || (!(kp.need_eb || kp.need_rb) && kp.mode != 3)) ? 4
                                       // nested R-hat only needs the moments (and has no ess_rhat twin whose bits it must match)
-                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : 0)),
+                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : (long_chain ? ((kp.need_eb && kp.ess_ok) ? 3 : 2) : 0))),
                                   // the folded ranking that follows is a merge of the sorted slice (fold_merge_phase)
                                   kp.need_rt && kp.mode != 3 && kp.fold_merge);
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
@@ -781,8 +787,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // bits whichever autocovariance path follows
             if (many) { // time-order scores, one thread per split chain
                 so.rhat = rhat_many_phase<double>(kp, zb, xs, smem); so.ess = nan;
-            } else if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat)
-                so.rhat = nan; so.ess = nan;
+            } else if (rk == 4) { // long chains: moments from the ranking, lag products from its windowed score layout
+                so = series_win_phase(kp, zb, pbuf, bb, smem);
+                so.ess = fft_const_chain_nan(so.ess);
+            } else if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat, long chains without ESS)
+                so.ess = nan;
+                if (tid == 0) series_combine(kp, smem, 0, 1, false);
+                __syncthreads();
+                so.rhat = scal[2];
+                __syncthreads();
             } else if (acov && fft_lds) {
                 (void)series_z_phase<false>(kp, zb, nullptr, false, smem);
                 so = series_fft_phase(kp, YZ, smem);

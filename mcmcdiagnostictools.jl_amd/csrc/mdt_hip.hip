@@ -594,6 +594,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
             return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
     }
     { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
+    { const char* wo = getenv("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;

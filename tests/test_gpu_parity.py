@@ -976,3 +976,37 @@ def test_shard_size_config5_f32_nested_and_mcse(pkg):
     assert_close(full[0][pick], co.mcse_mean(xs), 1e-6, "cfg5 mcse")
     assert_close(full[1][pick], co.rhat_nested(xs, inds, kind="rank"), 1e-6, "cfg5 nested")
     assert np.all(full[1] >= 1.0) and np.all(full[1] < 1.01)  # the shared initial values are forgotten after 10 000 draws
+
+
+def test_long_chains_windowed_layout(pkg, methods, monkeypatch):
+    """chains that do not fit the LDS: the ranking keeps its scores in partition order with a run table and halo strips,
+    series_win_phase gathers time windows from them (no time-order scatter).  Against the oracle, and against the
+    time-order route (MDT_WINOUT=0): the moments differ in their fixed-point shift only, so 1e-12; chain starts that
+    do not fall on partition-tile boundaries, three splits, all three autocovariance methods, maxlag up to the cap,
+    Float32, both geometries, R-hat only"""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(4242)
+    cases = [(30011, 3, 2, np.float64, 250), (20000, 2, 3, np.float64, 250), (70001, 2, 2, np.float64, 1000), (26000, 5, 1, np.float32, 100)]
+    for D, C, s, dt, ml in cases:
+        x = np.concatenate([rng.standard_normal((D, C, 2)), ar1(0.9, D, C, 2, rng), ar1(-0.4, D, C, 1, rng)], axis=2).astype(dt)
+        x[:, 0, 3] += 0.3
+        xd = dev(x)
+        tol = RTOL64 if dt == np.float64 else 1e-6
+        for mname in ("direct", "fft", "bda"):
+            got = {}
+            for sw in ("1", "0"):
+                monkeypatch.setenv("MDT_WINOUT", sw)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    got[sw] = [host(o) for o in pkg.bulk_tail(xd, autocov_method=methods[mname], split_chains=s, maxlag=ml)]
+                    got[sw].append(host(pkg.rhat(xd, kind="rank", split_chains=s)))
+                    got[sw].append(host(pkg.ess(xd, kind="bulk", autocov_method=methods[mname], split_chains=s, maxlag=ml)))
+            monkeypatch.delenv("MDT_WINOUT")
+            for a, b in zip(got["1"], got["0"]):
+                assert_close(a, b, 1e-12, f"windowed vs time order {D}x{C} s={s} {mname}")
+            assert np.array_equal(got["1"][4], np.maximum(got["1"][2], got["1"][3]))     # rhat(rank) == max(bulk, tail), same bits
+            assert np.array_equal(got["1"][5], got["1"][0])                               # ess(bulk) == fused bulk ESS
+            want = co.bulk_tail(x, autocov=mname, split_chains=s, maxlag=ml)
+            for a, b, nm in zip(got["1"], want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+                assert_close(a, b, tol, f"{nm} {D}x{C} s={s} {mname} {np.dtype(dt).name}")
