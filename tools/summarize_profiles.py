@@ -1,12 +1,22 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), f"profiles/{tag}_bench.json")
 for f in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
-    shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+    with open(f) as fi, open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:   # (torch's generator kernels have names of several KB)
+        w = csv.writer(fo)
+        for row in csv.reader(fi):
+            row[0] = row[0][:100]
+            w.writerow(row)
+for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "strided", "kinds"):
+    p = os.path.join(src, name + ".txt")
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, f"profiles/{tag}_{name}.txt")
+
+
 def rows(d, pat):
     out = []
     for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
@@ -14,26 +24,47 @@ def rows(d, pat):
             if pat in r["Kernel_Name"]:
                 out.append(r)
     return out
+
+
 def mean(d, pat):
     v = [float(r["Counter_Value"]) for r in rows(d, pat)]
-    return sum(v) / len(v)
-fetch_kb, write_kb = mean("pmc_fetch", "mdt_kernel"), mean("pmc_write", "mdt_kernel")
+    return sum(v) / len(v) if v else float("nan")
+
+
 cal = {}
 for d, key in (("pmc_fetch_cal", "fetch"), ("pmc_write_cal", "write")):
     rs = [r for r in rows(d, "copy8") if int(r["Grid_Size"]) // int(r["Workgroup_Size"]) == 256 and r["Workgroup_Size"] == "1024"]
     known_kb = 256 * 40000 * 8 * 20 / 1024
     cal[key] = sum(float(r["Counter_Value"]) for r in rs) / len(rs) / known_kb
-for d in ("pmc_fetch", "pmc_write", "pmc_fetch_cal", "pmc_write_cal"):
-    with open(f"profiles/{tag}_{d}.csv", "w") as fo:
-        w = csv.writer(fo); w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
-        for r in rows(d, "mdt_kernel") + rows(d, "copy8"):
-            w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
-traffic = fetch_kb * 1024 / cal["fetch"] + write_kb * 1024 / cal["write"]
-out = {"draws": 10000, "chains": 4, "params": 10000, "kernel": "mdt_kernel<double>",
-       "FETCH_SIZE_KB_raw": fetch_kb, "WRITE_SIZE_KB_raw": write_kb,
-       "calibration": {"fetch_counter_over_known": cal["fetch"], "write_counter_over_known": cal["write"],
+WORK = {"cfg2": (10000, 4, 10000, 8, 1, "mdt_small::mdt_kernel<double>"), "cfg3": (100000, 8, 1000, 8, 1, "mdt_big::mdt_kernel<double>"),
+        "cfg5": (10000, 16, 12500, 4, 2, "mdt_small::mdt_kernel<float> (mcse(mean) + rhat_nested(rank): two launches)")}
+out = {"calibration": {"fetch_counter_over_known": cal["fetch"], "write_counter_over_known": cal["write"],
                        "how": "same session, tools/scatter_bench copy8 (8 B/lane coalesced, 256 WG x 1024 threads, 6.55 GB known each way)"},
-       "hbm_bytes_per_launch": traffic,
-       "note": "memory-side (L2<->fabric) bytes per launch; Infinity-Cache hits are included (upper bound on HBM traffic). Algorithmic bytes per launch: 3.2e9."}
-json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+       "note": "memory-side (L2<->fabric) bytes; Infinity-Cache hits are included (upper bound on HBM traffic)"}
+for c, (D, C, P, ts, launches, kern) in WORK.items():
+    with open(f"profiles/{tag}_pmc_{c}.csv", "w") as fo:
+        w = csv.writer(fo)
+        w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
+        for d in (f"pmc_fetch_{c}", f"pmc_write_{c}"):
+            for r in rows(d, "mdt_kernel"):
+                w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
+    f_kb, w_kb = mean(f"pmc_fetch_{c}", "mdt_kernel"), mean(f"pmc_write_{c}", "mdt_kernel")
+    per_launch = f_kb * 1024 / cal["fetch"] + w_kb * 1024 / cal["write"]
+    alg = P * (D * C * ts) * launches
+    out[c] = {"draws": D, "chains": C, "params": P, "kernel": kern, "FETCH_SIZE_KB_raw_per_launch": f_kb, "WRITE_SIZE_KB_raw_per_launch": w_kb,
+              "memory_side_bytes_per_launch": per_launch, "memory_side_bytes_per_call": per_launch * launches,
+              "algorithmic_bytes_per_call": alg, "traffic_over_algorithmic": per_launch * launches / alg}
+with open(f"profiles/{tag}_pmc_cal.csv", "w") as fo:
+    w = csv.writer(fo)
+    w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
+    for d in ("pmc_fetch_cal", "pmc_write_cal"):
+        for r in rows(d, "copy8"):
+            w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
+# the file bench.py reads for roofline.traffic (headline workload)
+t2 = out["cfg2"]
+json.dump({"draws": 10000, "chains": 4, "params": 10000, "kernel": t2["kernel"], "FETCH_SIZE_KB_raw": t2["FETCH_SIZE_KB_raw_per_launch"],
+           "WRITE_SIZE_KB_raw": t2["WRITE_SIZE_KB_raw_per_launch"], "calibration": out["calibration"],
+           "hbm_bytes_per_launch": t2["memory_side_bytes_per_launch"], "profile": tag,
+           "note": out["note"] + ". Algorithmic bytes per launch: 3.2e9.", "other_workloads": {k: out[k] for k in ("cfg3", "cfg5")}},
+          open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
