@@ -4,7 +4,7 @@ Purpose: a second opinion for oracle/mdt_oracle.c.  It deliberately uses differe
 blocks (scipy.stats.rankdata, scipy.special.ndtri, numpy.fft with a power-of-two pad,
 numpy.quantile, numpy.median) so that an error in reading the reference would have to be made
 twice, differently, to go unnoticed.  The two must agree to <= 1e-10 relative on the golden
-inputs (tests/test_oracle_cross.py); the golden vectors in tests/golden/ are minted from both
+inputs (tests/test_oracle_golden.py::test_numpy_oracle_matches_golden); the golden vectors in tests/golden/ are minted from both
 (tests/golden/make_golden.py).  Float64 only.  Never imported by the product.
 
 Reference lines restated (relative to /root/reference): src/ess_rhat.jl:161-213, 301-311,
