@@ -674,7 +674,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
             else rank_phase_b<unsigned>(kp, VX, n, smem, zb, pbuf, bb, ntgt, kp.mode == 3);
         }
-        // the ranking left the slice sorted, tags in sorted order, no ties, no NaN (rank_phase_q, srt)
+        // the ranking left the slice sorted, tags in sorted order, no NaN (rank_phase_q, srt)
         const bool sorted_ok = need_rank_x && kp.rank_variant == 2 && rk != 0 && uni(((int*)(smem + OFF_INTS))[18]) != 0;
         MDT_PROF_MARK(PH_RANKX);
         if (kp.mode == 5) { // _mcse_quantile (src/mcse.jl:109-117): half the distance of two order statistics, in T
@@ -818,7 +818,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
             rk = 0;
-            if (sorted_ok && (medT - medT == (T)0)) rk = fold_merge_phase<T>(kp, medT, n, smem, xs, bs);
+            if (sorted_ok && (medT - medT == (T)0)) rk = fold_merge_phase<T>(kp, medT, n, smem, xs, bs, bb);
             if (rk != 3) rank_folded(0, kp.mode != 3 ? 2 : 0);
             MDT_PROF_MARK(PH_RANKF);
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them

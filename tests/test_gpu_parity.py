@@ -731,7 +731,8 @@ def _fold_cases(rng, D, C):
     few = rng.uniform(0.25, 0.75, n)
     few[:30] = 1e-17 * np.arange(1, 31)                                         # ... and a few rounded together (the exact pass)
     cols.append(rng.permutation(few))
-    cols.append(np.round(rng.standard_normal(n) * 4) / 4)                       # ties in x itself
+    cols.append(np.round(rng.standard_normal(n) * 4) / 4)                       # heavy ties in x itself: the general ranking
+    cols.append(np.round(rng.standard_normal(n) * 1e5) / 1e5)                   # a few hundred tied pairs in x: sorted side by side, exact pass
     inf = rng.standard_normal(n)
     inf[17] = np.inf
     inf[n - 5] = -np.inf
