@@ -609,8 +609,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 const double r = nested_combine_wg(kp, mean_j, var_j, smem);
                 if (tid == 0) store_out<T>(kp.out_rb, p, r);
                 __syncthreads();
+            } else if (kp.mode == 2 && kp.rem == 0) {
+                // pooled corrected std over all draws and chains (src/mcse.jl:50).  Every draw belongs to a split chain
+                // here, so the pooled moments follow from the split-chain ones already in LDS (Chan's combination:
+                // sum of squares about the pooled mean = sum_j [(niter - 1) var_j + niter (mean_j - mu)^2]) -- no further
+                // pass over x
+                if (tid == 0) {
+                    double mu = 0.0;
+                    for (int j = 0; j < kp.m; ++j) mu += mean_j[j];
+                    mu /= (double)kp.m;
+                    double ss = 0.0;
+                    for (int j = 0; j < kp.m; ++j) { const double d = mean_j[j] - mu; ss += (double)(kp.niter - 1) * var_j[j] + (double)kp.niter * d * d; }
+                    store_out<T>(kp.out_eb, p, sqrt(ss / (double)(n - 1)) / sqrt(ess));
+                }
+                __syncthreads();
             } else if (kp.mode == 2) {
-                // pooled corrected std over all draws and chains (src/mcse.jl:50)
+                // (rows dropped by the split, D % split_chains != 0: two passes over the pooled slice)
                 double loc = 0.0;
                 for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
                 const double mu = wg_sum(loc, red) / (double)n;
