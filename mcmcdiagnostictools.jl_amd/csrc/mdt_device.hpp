@@ -802,7 +802,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             if (many) { // time-order scores, one thread per split chain
                 so.rhat = rhat_many_phase<double>(kp, zb, xs, smem); so.ess = nan;
             } else if (rk == 4) { // long chains: moments from the ranking, lag products from its windowed score layout
-                so = series_win_phase(kp, zb, pbuf, bb, smem);
+                bits_done = zq_ok && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
+                so = series_win_phase(kp, zb, pbuf, bb, smem, bits_done ? gb : nullptr, zq[0], zq[1]);
                 so.ess = fft_const_chain_nan(so.ess);
             } else if (rk == 3) { // the ranking delivered mean_j / var_j itself (nested R-hat, long chains without ESS)
                 so.ess = nan;
@@ -854,7 +855,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
             else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
                 et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);
-            else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem);
+            else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);
             MDT_PROF_MARK(PH_IND);
         }
         if (((int*)(smem + OFF_INTS))[19]) { eb = nan; rb = nan; et = nan; rt = nan; } // ranking tables overflowed (status bit 0)

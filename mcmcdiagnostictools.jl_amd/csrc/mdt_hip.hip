@@ -447,14 +447,14 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     const bool indicators = rq.need_et || rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE;
-    if (indicators && D > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws > 131072 not supported for indicator ESS (tail, median, mad, quantile)");
+    if (indicators && niter > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws / split_chains > 131072 not supported for indicator ESS (tail, median, mad, quantile)");
     // (FFTAutocovMethod beyond 8192 padded points: the same linear autocorrelation from lagged products, see the kernel)
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
     const bool fft_lds = fft && getenv("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
-                            D <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
+                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
     // short slices: four 256-thread workgroups per CU (40 KiB of LDS each) -- a parameter of a few thousand values
     // is mostly barrier and latency chains, which twice as many resident workgroups hide twice as well
     int force_cfg = ctx->force_cfg; // MDT_CONFIG is honoured per request (tests switch it between calls)
@@ -462,7 +462,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     else force_cfg = 0;
     // (measured: 1000 x 4 x 100 000 19.5 ms against 31.8 with two 512-thread workgroups per CU, 200 x 4 x 500 000 57 against
     // 132, 1000 x 12 x 30 000 28.4 against 36.1; no gain once a split chain no longer fits the z-series buffer)
-    const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 40 <= mdt_tiny::SZ && D <= (long long)mdt_tiny::BITW * 64 &&
+    const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 40 <= mdt_tiny::SZ && niter <= (long long)mdt_tiny::BITW * 64 &&
                            (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
     const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU

@@ -1011,3 +1011,23 @@ def test_long_chains_windowed_layout(pkg, methods, monkeypatch):
             want = co.bulk_tail(x, autocov=mname, split_chains=s, maxlag=ml)
             for a, b, nm in zip(got["1"], want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
                 assert_close(a, b, tol, f"{nm} {D}x{C} s={s} {mname} {np.dtype(dt).name}")
+
+
+def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
+    """the indicator phase holds one SPLIT chain's bits at a time (round 2): draws / split_chains <= 131 072 instead of
+    draws <= 131 072; both routes to the bits (from the windows of the z-series, from x itself) against the oracle"""
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(99)
+    x = np.concatenate([rng.standard_normal((200_000, 2, 1)), ar1(0.8, 200_000, 2, 1, rng)], axis=2)
+    xd = dev(x)
+    want = co.bulk_tail(x)
+    for sw in (None, "1"):
+        if sw:
+            monkeypatch.setenv("MDT_NO_IBITS", sw)
+        got = [host(o) for o in pkg.bulk_tail(xd)]
+        for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+            assert_close(a, b, RTOL64, f"{nm} 200000 draws, bits from {'x' if sw else 'the z-series'}")
+        assert_close(host(pkg.ess(xd, kind=np.median)), co.ess_estimator(x, "median"), RTOL64, "ess median 200000 draws")
+    monkeypatch.delenv("MDT_NO_IBITS")
+    with pytest.raises(NotImplementedError):
+        pkg.ess(dev(rng.standard_normal((300_000, 1, 1))), kind="tail", split_chains=1)
