@@ -103,8 +103,8 @@ const char* mdt_last_error(const mdt_ctx* ctx);
 
 /*
  * One context over several GPUs of the node: every parameter is independent (the `for` over
- * _eachparam, src/ess_rhat.jl:517), so mdt_ess_rhat / mdt_bulk_tail / mdt_rhat_nested / mdt_mcse_mean on such a
- * context cut the params axis into ndev contiguous blocks (block i = params [i*P/ndev, (i+1)*P/ndev)), run block
+ * _eachparam, src/ess_rhat.jl:517), so mdt_ess_rhat (every kind and estimator) / mdt_bulk_tail / mdt_rhat_nested /
+ * mdt_mcse_mean / mdt_mcse_std on such a context cut the params axis into ndev contiguous blocks (block i = params [i*P/ndev, (i+1)*P/ndev)), run block
  * i on device_ids[i] concurrently (one host thread and one stream per device, no exchange during compute) and
  * leave every output vector complete in the caller's buffer.  location == MDT_HOST: each block is staged to its
  * own GPU over PCIe.  location == MDT_DEVICE: x and the outputs live on ONE of the devices (found from the

@@ -679,7 +679,7 @@ int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq) {
     if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
     if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "a multi-GPU context takes the dense layout only");
-    if (rq.mode > 2 || rq.est || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
+    if ((rq.mode > 2 && rq.mode != 4) || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     const long long P = a->params;
     if (P == 0) return MDT_OK;
     if (!x) return fail(ctx, MDT_EARG, "x is NULL");

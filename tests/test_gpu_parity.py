@@ -930,6 +930,10 @@ def test_multi_gpu_context_and_current_device(pkg):
     ids = [1, 1, 2, 2]
     assert np.array_equal(host(pkg.rhat_nested(xd, ids, devices=devices)), host(pkg.rhat_nested(xd, ids)))
     assert np.array_equal(host(pkg.mcse(xd, devices=devices)), host(pkg.mcse(xd)))
+    assert np.array_equal(host(pkg.mcse(xd, kind=np.std, devices=devices)), host(pkg.mcse(xd, kind=np.std)))
+    assert np.array_equal(host(pkg.ess(xd, kind=np.median, devices=devices)), host(pkg.ess(xd, kind=np.median)))
+    with pytest.raises(NotImplementedError):
+        pkg.mcse(xd, kind=np.median, devices=devices)       # (two device passes with context-owned buffers: one GPU at a time)
     r = pkg.ess_rhat(x, devices=devices)
     r0 = pkg.ess_rhat(xd)
     assert np.array_equal(host(r.ess), host(r0.ess)) and np.array_equal(host(r.rhat), host(r0.rhat))
