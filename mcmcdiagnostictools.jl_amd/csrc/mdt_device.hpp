@@ -19,7 +19,14 @@
 //                 (:555-594) runs on one lane between blocks, so well-mixed chains stop after 32 lags.  The
 //                 moments of a rank-normalised series are exact fixed-point sums (order independent).
 //   indicator     tail-ESS (src/ess_rhat.jl:301-311, 647-659): the quantile indicators are bit-vectors, their
-//                 autocovariance is popcount(bits & bits>>k), exact integers.
+//                 autocovariance is popcount(bits & bits>>k), exact integers.  In the fused request the bits come from
+//                 the z-series while a chain sits in LDS (scores are strictly increasing in the rank).
+//   fold merge    rhat(kind = :tail) ranks |x - median|: the ranking of x leaves the slice sorted, the folded values are
+//                 two monotone runs mirrored at the median, their ranks are those of a two-way merge (mdt_fold.inc).
+//   long chains   chains that do not fit the LDS: scores stay in partition order with a (tile, round) run table and halo
+//                 strips; series_win_phase gathers time windows from them (mdt_series.inc).
+//   many chains   chains * split_chains > 256: R-hat / nested R-hat with one thread per split chain; the nested
+//                 combination sums in sorted order (permutation-invariant bit for bit) (mdt_nested.inc).
 //
 // Everything is deterministic (no floating-point atomics), which the reference's tests demand
 // (test/ess_rhat.jl:167-204: results identical wherever a parameter sits in the batch).
@@ -91,9 +98,8 @@ constexpr int OFF_PART = OFF_AUX + 2 * NLAGTAB * 8;       // double part[NWAVE*8
 constexpr int OFF_SER = OFF_PART + NWAVE * 8 * 8;         // double ser[TL+HALO]
 constexpr int LDS_SER_END = OFF_SER + (TL + HALO) * 8;
 // indicator phase view of the big region
-constexpr int OFF_BITS = OFF_BIG;                         // uint64 bits[2][BITW]  raw ballots of one chain
-constexpr int BITW = TINY ? 512 : SMALL ? 1024 : 2048;    // => draws <= 32768 / 65536 / 131072
-constexpr int OFF_SBITS = OFF_BITS + 2 * BITW * 8;        // uint64 sbits[2][BITW] split-aligned words
+constexpr int BITW = TINY ? 1024 : SMALL ? 2048 : 4096;   // => draws / split_chains <= 65536 / 131072 / 262144
+constexpr int OFF_SBITS = OFF_BIG;                        // uint64 sbits[2][BITW] words of one split chain, aligned to its first draw
 constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
 constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})
 constexpr int OFF_IVAR = OFF_IDIF + 2 * NLAGTAB * 8;      // double imean[2][MAXM]

@@ -1018,7 +1018,7 @@ def test_long_chains_windowed_layout(pkg, methods, monkeypatch):
 
 
 def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
-    """the indicator phase holds one SPLIT chain's bits at a time (round 2): draws / split_chains <= 131 072 instead of
+    """the indicator phase holds one SPLIT chain's bits at a time (round 2): draws / split_chains <= 262 144 instead of
     draws <= 131 072; both routes to the bits (from the windows of the z-series, from x itself) against the oracle"""
     from oracle import c_oracle as co
     rng = np.random.default_rng(99)
@@ -1035,3 +1035,4 @@ def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
     monkeypatch.delenv("MDT_NO_IBITS")
     with pytest.raises(NotImplementedError):
         pkg.ess(dev(rng.standard_normal((300_000, 1, 1))), kind="tail", split_chains=1)
+    assert np.isfinite(host(pkg.ess(dev(rng.standard_normal((300_000, 1, 1))), kind="tail"))).all()   # niter = 150 000
