@@ -2,7 +2,7 @@
 //
 // StatsFuns.betainvcdf as used by src/mcse.jl:105-106 (quadrature points of the Beta error distribution) and,
 // through Distributions.quantile(FDist(d1, d2), q) = d2 y / (d1 (1 - y)), y = betainvcdf(d1/2, d2/2, q), by
-// src/gelmandiag.jl:50.  Continued fraction of I_x(a, b) + safeguarded Newton; agrees with
+// src/gelmandiag.jl:50.  Continued fraction of I_x(a, b) + safeguarded Halley / Newton; agrees with
 // scipy.special.betaincinv to ~1e-11 (tests/test_host_api.py).
 #pragma once
 #include <math.h>
@@ -87,7 +87,13 @@ MDT_HD static inline double mdt_betainvcdf(double a, double b, double p, double 
         const double f = mdt_ibeta_lb(a, b, x, lb) - p;
         if (f > 0.0) hi = x; else lo = x;
         const double pdf = (x > 0.0 && x < 1.0) ? exp((a - 1.0) * log(x) + (b - 1.0) * log1p(-x) - lb) : 0.0;
-        double xn = (pdf > 0.0) ? x - f / pdf : 0.5 * (lo + hi);
+        // Halley's step (the density's logarithmic derivative is two divisions): cubic convergence -- every step costs a
+        // continued fraction, and this loop runs one thread per parameter; plain Newton where the correction is wild
+        double xn = 0.5 * (lo + hi);
+        if (pdf > 0.0) {
+            const double nt = f / pdf, g = (a - 1.0) / x - (b - 1.0) / (1.0 - x), den = 1.0 - 0.5 * nt * g;
+            xn = x - ((den > 0.5 && den < 2.0) ? nt / den : nt);
+        }
         if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
         if (fabs(xn - x) <= 4e-16 * x) { x = xn; break; } /* (two neighbouring doubles would otherwise alternate until the cap) */
         x = xn;
