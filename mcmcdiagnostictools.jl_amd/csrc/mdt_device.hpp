@@ -602,12 +602,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 __syncthreads();
                 continue;
             }
-            SeriesOut so = series_z_phase<false, true, T>(kp, xp, nullptr, false, smem);
+            // (a split chain that fits the LDS: the autocovariance sweep takes the moments itself, from the chain it holds --
+            // same virtual threads, order and expressions as the streaming sweep, so the same bits -- one pass over x less)
+            const bool fuse = acov && zfast && !fft_lds;
+            SeriesOut so;
+            if (!fuse) so = series_z_phase<false, true, T>(kp, xp, nullptr, false, smem);
             if (acov) {
                 SeriesOut sa;
                 if (fft_lds) sa = series_fft_phase(kp, YX, smem);
-                else if (zfast) sa = series_z_phase<false, true, T>(kp, xp, nullptr, true, smem);
+                else if (zfast) sa = series_z_phase<false, true, T>(kp, xp, nullptr, true, smem, nullptr, 0.0, 0.0, true);
                 else sa = series_phase(kp, YX, true, smem, true);
+                if (fuse) so.rhat = sa.rhat;
                 so.ess = fft_lds ? sa.ess : fft_const_chain_nan(sa.ess);
             }
             double ess = acov ? so.ess : nan;
