@@ -25,8 +25,8 @@
 //                 two monotone runs mirrored at the median, their ranks are those of a two-way merge (mdt_fold.inc).
 //   long chains   chains that do not fit the LDS: scores stay in partition order with a (tile, round) run table and halo
 //                 strips; series_win_phase gathers time windows from them (mdt_series.inc).
-//   many chains   chains * split_chains > 256: R-hat / nested R-hat with one thread per split chain; the nested
-//                 combination sums in sorted order (permutation-invariant bit for bit) (mdt_nested.inc).
+//   many chains   chains * split_chains > 256: moments, R-hat and ESS with one thread per split chain (many_phase); the
+//                 nested combination sums in sorted order (permutation-invariant bit for bit) (mdt_nested.inc).
 //
 // Everything is deterministic (no floating-point atomics), which the reference's tests demand
 // (test/ess_rhat.jl:167-204: results identical wherever a parameter sits in the batch).
@@ -263,6 +263,19 @@ struct SerSq {         // series = (x - mean)^2 evaluated in T: the expectand pr
     __device__ __forceinline__ double operator()(int c, long long row) const {
         const T d = (T)(xp[(long long)c * D + row] - mu);
         return (double)(T)(d * d);
+    }
+};
+template <typename T>
+struct SerInd {        // series = 1[x <= thr] or 1[|x - med| <= thr], compared in T: the expectand proxy of median / mad / quantile
+    const MDT_GA T* xp; // (src/ess_rhat.jl:630-659); only where the indicator phases' tables do not reach (many_phase)
+    long long D;
+    T thr, med;
+    int fold;
+    __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); D = uni(D); thr = uni(thr); med = uni(med); fold = uni(fold); }
+    __device__ __forceinline__ double operator()(int c, long long row) const {
+        T v = xp[(long long)c * D + row];
+        if (fold) { const T d = (T)(v - med); v = d < (T)0 ? -d : d; }
+        return (v <= thr) ? 1.0 : 0.0;
     }
 };
 struct SerZ {          // series = normal scores, already in time order in the per-workgroup scratch
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             xp = xc;
         }
         if (tid == 0) ((int*)(smem + OFF_INTS))[19] = 0; // set when the ranking tables overflow: the parameter's outputs become NaN
-        const bool many = kp.m > MAXM; // more split chains than the LDS moment tables hold: R-hat only (rhat_many_phase)
+        const bool many = kp.m > MAXM; // more split chains than the LDS moment tables hold (many_phase)
         const SrcPlain<T> VX{(const MDT_GA T*)xp};
         const SerX<T> YX{(const MDT_GA T*)xp, D};
         const SerZ YZ{(const MDT_GA double*)zb, D};
@@ -570,7 +583,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
             const T muT = (T)(wg_sum(loc, red) / (double)n);
             const SerSq<T> YS{(const MDT_GA T*)xp, D, muT};
-            const SeriesOut so = basic_ess_rhat(YS, kp.ess_ok != 0);
+            const SeriesOut so = many ? many_phase(kp, YS, xs, kp.ess_ok != 0, smem) : basic_ess_rhat(YS, kp.ess_ok != 0);
             const double ess = kp.ess_ok ? so.ess : nan;
             if (kp.mode == 4) {
                 // src/mcse.jl:52-65: sqrt((E[mu4] / E[var] - E[var]) / S) / 2, E[var] = mean(proxy), E[mu4] = mean(proxy^2)
@@ -596,9 +609,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // rhat(x) and ess_rhat(x).rhat are the same bits; then the autocovariance: the in-LDS FFT if asked
             // for, the one-chain-per-LDS-buffer sweep when a split chain fits, the tiled series_phase otherwise
             const bool acov = kp.need_eb && kp.ess_ok;
-            if (many) { // (R-hat or nested R-hat of the raw draws; the host refuses ESS with this many chains)
-                const double r = rhat_many_phase<T>(kp, xp, xs, smem);
-                if (tid == 0) { store_out<T>(kp.out_eb, p, nan); store_out<T>(kp.out_rb, p, r); }
+            if (many) { // more split chains than the moment tables hold: one thread per split chain (many_phase)
+                const SeriesOut sm = many_phase(kp, YX, xs, acov, smem);
+                const double ess = acov ? sm.ess : nan;
+                if (kp.mode == 2) { // pooled corrected std over all draws and chains (src/mcse.jl:50), two passes
+                    double loc = 0.0;
+                    for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
+                    const double mu = wg_sum(loc, red) / (double)n;
+                    loc = 0.0;
+                    for (long long e = tid; e < n; e += NT) { const double d = (double)xp[e] - mu; loc = fma(d, d, loc); }
+                    const double var = wg_sum(loc, red) / (double)(n - 1);
+                    if (tid == 0) store_out<T>(kp.out_eb, p, sqrt(var) / sqrt(ess));
+                } else if (tid == 0) {
+                    if (kp.mode != 1) store_out<T>(kp.out_eb, p, ess);
+                    store_out<T>(kp.out_rb, p, sm.rhat);
+                }
                 __syncthreads();
                 continue;
             }
@@ -693,7 +718,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                                       // nested R-hat only needs the moments (and has no ess_rhat twin whose bits it must match)
                                       : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : (long_chain ? ((kp.need_eb && kp.ess_ok) ? 3 : 2) : 0))),
                                   // the folded ranking that follows is a merge of the sorted slice (fold_merge_phase)
-                                  kp.need_rt && kp.mode != 3 && kp.fold_merge);
+                                  kp.need_rt && kp.mode != 3 && kp.fold_merge && !many); // (many chains: the sorted copy's scratch holds their moments)
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             } else if (kp.rank_variant == 1) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
             else if (pos16) rank_phase_b<unsigned short>(kp, VX, n, smem, zb, (unsigned short*)pbuf, bb, ntgt, kp.mode == 3);
@@ -783,6 +808,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                     __syncthreads();
                 }
                 if (kp.est == 7 && thr != thr) { if (tid == 0) atomicOr(kp.status, 2); } // Statistics.quantile throws on NaN
+                else if (many) ee = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, thr, medT, fold}, xs, true, smem).ess;
                 else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
                     ee = indicator_phase_pooled<T>(kp, xp, thr, thr, smem, fold, medT);
                 else ee = indicator_phase<T>(kp, xp, (double)thr, (double)thr, smem, fold, medT);
@@ -811,7 +837,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
             // bits whichever autocovariance path follows
             if (many) { // time-order scores, one thread per split chain
-                so.rhat = rhat_many_phase<double>(kp, zb, xs, smem); so.ess = nan;
+                so = many_phase(kp, YZ, xs, acov, smem);
             } else if (rk == 4) { // long chains: moments from the ranking, lag products from its windowed score layout
                 bits_done = zq_ok && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
                 so = series_win_phase(kp, zb, pbuf, bb, smem, bits_done ? gb : nullptr, zq[0], zq[1]);
@@ -850,7 +876,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
             // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores
             if (many) {
-                rt = rhat_many_phase<double>(kp, zb, xs, smem);
+                rt = many_phase(kp, YZ, xs, false, smem).rhat;
             } else if (rk == 3) {
                 if (tid == 0) series_combine(kp, smem, 0, 1, false);
                 __syncthreads();
@@ -864,7 +890,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         if (kp.need_et && kp.ess_ok) {
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
-            else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
+            else if (many) { // min over the two tails of the basic ESS of the indicator (src/ess_rhat.jl:301-311)
+                const double e0 = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, qloT, (T)0, 0}, xs, true, smem).ess;
+                const double e1 = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, qhiT, (T)0, 0}, xs, true, smem).ess;
+                et = jl_min(e0, e1);
+            } else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
                 et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);
             else et = indicator_phase<T>(kp, xp, (double)qloT, (double)qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);
             MDT_PROF_MARK(PH_IND);

@@ -438,11 +438,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         return fail(ctx, MDT_EARG, "quantile probability must be in [0, 1]"); // Statistics.quantile
     // engine limits
     static_assert(mdt_big::MAXM == mdt_small::MAXM && mdt_big::MAXM == mdt_tiny::MAXM, "one limit for all geometries");
-    // more split chains than the LDS moment tables hold (many short chains, what nested R-hat is for): R-hat and
-    // nested R-hat of any kind run with one thread per split chain (rhat_many_phase); ESS needs the tables
+    // more split chains than the LDS moment tables hold (many short chains, what nested R-hat is for): every kind runs
+    // with one thread per split chain (many_phase), its moments in the scratch of the sorted copy
     const bool many = m > mdt_big::MAXM;
-    if (many && (rq.want_ess || rq.est || (rq.mode != 0 && rq.mode != 1) || rq.need_eb || rq.need_et))
-        return fail(ctx, MDT_EUNSUPPORTED, "ESS with chains*split_chains > 256 is not supported (R-hat and nested R-hat are)");
     if (many && 2 * m > n) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 needs at least 2*split_chains draws");
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");

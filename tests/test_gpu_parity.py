@@ -772,7 +772,7 @@ def test_fold_merge_matches_general_ranking(pkg, monkeypatch, dtype):
 def test_rhat_many_chains(pkg):
     """more split chains than the LDS moment tables hold (chains*split_chains > 256): the reference's own suite runs
     rhat_nested on 10 draws x 2048 chains x 32 params in 8 and 16 superchains and asks 1 < R < 1.001
-    (test/rhat_nested.jl:157-169); rhat of every kind takes the same route; ESS there is refused, not approximated"""
+    (test/rhat_nested.jl:157-169); rhat of every kind takes the same route (ESS: test_ess_many_chains)"""
     from oracle import c_oracle as co
     rng = np.random.default_rng(2048)
     x = rng.standard_normal((10, 2048, 32))
@@ -797,10 +797,57 @@ def test_rhat_many_chains(pkg):
     for kind in KINDS:
         assert_close(host(pkg.rhat_nested(dev(y), ids, kind=kind)), co.rhat_nested(y, inds, kind=kind), 1e-6, f"nested f32 {kind}")
         assert_close(host(pkg.rhat(dev(y), kind=kind)), co.ess_rhat(y, kind=kind)[1], 1e-6, f"rhat f32 {kind}")
-    with pytest.raises(NotImplementedError):
-        pkg.ess(xd)
-    with pytest.raises(NotImplementedError):
-        pkg.mcse(xd)
+
+
+def test_ess_many_chains(pkg, methods):
+    """ESS of every kind, the estimator kinds and mcse with more split chains than the LDS moment tables hold
+    (chains*split_chains > 256; refused until round 2): one thread per split chain (many_phase) against the oracle;
+    rhat(x) and ess_rhat(x)[1] stay the same bits (test/ess_rhat.jl:167-204)"""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(4096)
+    cases = [(ar1(0.6, 40, 320, 3, rng) + 0.1 * rng.standard_normal((1, 320, 1)), RTOL64),           # m = 640, 20 draws per split chain
+             (ar1(0.3, 300, 200, 2, rng).astype(np.float32), 1e-6),                                  # two-level ranking (n = 60000), Float32
+             (np.round(ar1(0.5, 64, 150, 2, rng) * 4) / 4, RTOL64)]                                  # ties
+    for x, tol in cases:
+        xd = dev(x)
+        for s in (1, 2, 3):
+            if x.shape[1] * s <= 256:
+                continue
+            for kind in KINDS:
+                for mname in ("direct", "fft", "bda"):
+                    if mname != "direct" and (s != 2 or kind == "rank"):
+                        continue
+                    S, R = [host(o) for o in pkg.ess_rhat(xd, kind=kind, split_chains=s, autocov_method=methods[mname])]
+                    wS, wR = co.ess_rhat(x, kind=kind, split_chains=s, autocov=mname)
+                    assert_close(S, wS, tol, f"ess {x.shape} {kind} {s} {mname}")
+                    assert_close(R, wR, tol, f"rhat {x.shape} {kind} {s} {mname}")
+                    assert np.array_equal(R, host(pkg.rhat(xd, kind=kind, split_chains=s)), equal_nan=True)
+                    if kind != "rank":
+                        assert np.array_equal(S, host(pkg.ess(xd, kind=kind, split_chains=s, autocov_method=methods[mname])), equal_nan=True)
+            got = [host(o) for o in pkg.bulk_tail(xd, split_chains=s)]
+            for g_, w_, nm in zip(got, co.bulk_tail(x, split_chains=s), ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+                assert_close(g_, w_, tol, f"bulk_tail {x.shape} {s} {nm}")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for est, kind, prob in (("median", np.median, 0.5), ("std", np.std, 0.5), ("mad", "mad", 0.5), ("quantile", pkg.Quantile(0.2), 0.2)):
+                assert_close(host(pkg.ess(xd, kind=kind)), co.ess_estimator(x, est, prob=prob), tol, f"ess {est} {x.shape}")
+            assert_close(host(pkg.ess(xd, kind="bulk", relative=True, maxlag=7)), co.ess_rhat(x, kind="bulk", relative=True, maxlag=7)[0], tol, "relative, maxlag")
+            assert_close(host(pkg.mcse(xd)), co.mcse_mean(x), tol, f"mcse mean {x.shape}")
+            assert_close(host(pkg.mcse(xd, kind=np.std)), co.mcse_std(x), tol, f"mcse std {x.shape}")
+            assert_close(host(pkg.mcse(xd, kind=np.median)), co.mcse_quantile(x, "median"), tol, f"mcse median {x.shape}")
+            assert_close(host(pkg.mcse(xd, kind=pkg.Quantile(0.9))), co.mcse_quantile(x, "quantile", 0.9), tol, f"mcse q {x.shape}")
+    # a constant split chain: NaN under FFTAutocovMethod only (src/ess_rhat.jl:192), and too few draws: NaN ESS, R-hat kept
+    x = ar1(0.2, 24, 300, 2, rng)
+    x[:12, 5, 0] = 1.5
+    for mname in ("direct", "fft"):
+        S = host(pkg.ess(dev(x), kind="basic", autocov_method=methods[mname]))
+        assert_close(S, co.ess_rhat(x, kind="basic", autocov=mname)[0], RTOL64, "constant split chain " + mname)
+    assert np.isnan(host(pkg.ess(dev(x), kind="basic", autocov_method=methods["fft"]))[0])
+    x = rng.standard_normal((8, 2048, 4))
+    S, R = [host(o) for o in pkg.ess_rhat(dev(x))]
+    assert np.all(np.isnan(S))
+    assert_close(R, co.ess_rhat(x)[1], RTOL64, "rhat with too few draws for ESS")
 
 
 def test_rhat_nested_permutation_invariance_bitwise(pkg):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak test (needs a GPU; not part of the pytest suite): random shapes up to ~150 000 values per slice, splits,
-kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long]"""
+kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many]
+(long: chains of 50 000 - 131 072 draws; many: 100 - 1500 chains, more split chains than the LDS moment tables hold)"""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +15,7 @@ pkg = g.load_package()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
+MANY = len(sys.argv) > 3 and sys.argv[3] == "many"
 methods = {"direct": pkg.AutocovMethod(), "fft": pkg.FFTAutocovMethod(), "bda": pkg.BDAAutocovMethod()}
 
 
@@ -36,6 +38,9 @@ while time.time() - t0 < budget:
     P = int(rng.integers(1, 4))
     if LONG:  # long chains: the 1024-thread geometry, tiled partition over dozens of rounds, per-chain indicator ballots
         D, C, P = int(rng.integers(50000, 131072)), int(rng.integers(1, 9)), int(rng.integers(1, 3))
+    if MANY:  # many short chains (one thread per split chain)
+        C = int(rng.integers(100, 1500))
+        D, P = int(rng.integers(6, max(7, min(400, 150000 // C)))), int(rng.integers(1, 3))
     s = int(rng.integers(1, 4))
     fl = ("normal", "ar", "ties", "skew", "offset", "mass")[it % 6]
     if fl == "normal":
