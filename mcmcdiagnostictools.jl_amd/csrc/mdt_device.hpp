@@ -809,6 +809,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 }
                 if (kp.est == 7 && thr != thr) { if (tid == 0) atomicOr(kp.status, 2); } // Statistics.quantile throws on NaN
                 else if (many) ee = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, thr, medT, fold}, xs, true, smem).ess;
+                else if (kp.niter > (long long)BITW * 64) // (a split chain beyond the bit vectors of the indicator phases: the proxy, tiled)
+                    ee = basic_ess_rhat(SerInd<T>{(const MDT_GA T*)xp, D, thr, medT, fold}, true).ess;
                 else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
                     ee = indicator_phase_pooled<T>(kp, xp, thr, thr, smem, fold, medT);
                 else ee = indicator_phase<T>(kp, xp, (double)thr, (double)thr, smem, fold, medT);
@@ -893,6 +895,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             else if (many) { // min over the two tails of the basic ESS of the indicator (src/ess_rhat.jl:301-311)
                 const double e0 = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, qloT, (T)0, 0}, xs, true, smem).ess;
                 const double e1 = many_phase(kp, SerInd<T>{(const MDT_GA T*)xp, D, qhiT, (T)0, 0}, xs, true, smem).ess;
+                et = jl_min(e0, e1);
+            } else if (kp.niter > (long long)BITW * 64) { // (a split chain beyond the bit vectors of the indicator phases: the proxies, tiled)
+                const double e0 = basic_ess_rhat(SerInd<T>{(const MDT_GA T*)xp, D, qloT, (T)0, 0}, true).ess;
+                const double e1 = basic_ess_rhat(SerInd<T>{(const MDT_GA T*)xp, D, qhiT, (T)0, 0}, true).ess;
                 et = jl_min(e0, e1);
             } else if (n <= (long long)IND_MAXW * 64 && 2 * (((kp.niter + 63) >> 6) + (kp.maxlag >> 6) + 2) <= SB2_WORDS)
                 et = indicator_phase_pooled<T>(kp, xp, qloT, qhiT, smem, 0, (T)0, bits_done ? gb : nullptr);

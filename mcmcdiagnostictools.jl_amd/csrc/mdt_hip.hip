@@ -445,7 +445,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     const bool indicators = rq.need_et || rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE;
-    if (indicators && niter > (long long)mdt_big::BITW * 64) return fail(ctx, MDT_EUNSUPPORTED, "draws / split_chains > 262144 not supported for indicator ESS (tail, median, mad, quantile)");
+    // (split chains beyond the indicator phases' bit vectors, draws / split_chains > 262144: the indicator is evaluated as a
+    // proxy series by the tiled series_phase -- SerInd in mdt_device.hpp)
     // (FFTAutocovMethod beyond 8192 padded points: the same linear autocorrelation from lagged products, see the kernel)
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their

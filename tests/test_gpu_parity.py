@@ -1065,8 +1065,9 @@ def test_long_chains_windowed_layout(pkg, methods, monkeypatch):
 
 
 def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
-    """the indicator phase holds one SPLIT chain's bits at a time (round 2): draws / split_chains <= 262 144 instead of
-    draws <= 131 072; both routes to the bits (from the windows of the z-series, from x itself) against the oracle"""
+    """the indicator phase holds one SPLIT chain's bits at a time (round 2: draws / split_chains <= 262 144 instead of
+    draws <= 131 072); both routes to the bits (from the windows of the z-series, from x itself) against the oracle; longer
+    split chains take the indicator as a proxy series (no limit)"""
     from oracle import c_oracle as co
     rng = np.random.default_rng(99)
     x = np.concatenate([rng.standard_normal((200_000, 2, 1)), ar1(0.8, 200_000, 2, 1, rng)], axis=2)
@@ -1080,6 +1081,14 @@ def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
             assert_close(a, b, RTOL64, f"{nm} 200000 draws, bits from {'x' if sw else 'the z-series'}")
         assert_close(host(pkg.ess(xd, kind=np.median)), co.ess_estimator(x, "median"), RTOL64, "ess median 200000 draws")
     monkeypatch.delenv("MDT_NO_IBITS")
-    with pytest.raises(NotImplementedError):
-        pkg.ess(dev(rng.standard_normal((300_000, 1, 1))), kind="tail", split_chains=1)
     assert np.isfinite(host(pkg.ess(dev(rng.standard_normal((300_000, 1, 1))), kind="tail"))).all()   # niter = 150 000
+    # beyond the bit vectors (draws / split_chains > 262 144): the indicators as proxy series through the tiled series phase
+    y = np.concatenate([rng.standard_normal((300_000, 2, 1)), ar1(0.7, 300_000, 2, 1, rng)], axis=2)
+    yd = dev(y)
+    for m in ("direct", "bda"):
+        want = co.bulk_tail(y, split_chains=1, autocov=m)
+        got = [host(o) for o in pkg.bulk_tail(yd, split_chains=1, autocov_method=getattr(pkg, {"direct": "AutocovMethod", "bda": "BDAAutocovMethod"}[m])())]
+        for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+            assert_close(a, b, RTOL64, f"{nm} 300000 draws unsplit {m}")
+    for est, kind in (("median", np.median), ("mad", "mad"), ("quantile", pkg.Quantile(0.3))):
+        assert_close(host(pkg.ess(yd, kind=kind, split_chains=1)), co.ess_estimator(y, est, prob=0.3, split_chains=1), RTOL64, f"ess {est} 300000 draws unsplit")
