@@ -44,17 +44,27 @@ def main():
     ap.add_argument("--draws", type=int, default=10000)
     ap.add_argument("--chains", type=int, default=4)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--cfg5", action="store_true", help="BASELINE config 5's call: rhat_nested(kind = rank) on Float32, 16 chains in 4 superchains")
     a = ap.parse_args()
     pkg = g.load_package()
-    x = synth(a.draws, a.chains, a.params, torch.device("cuda", 0), 1234).permute(2, 1, 0)
-    pkg.bulk_tail(x)
+    if a.cfg5:
+        import numpy as np
+        from bench import synth_cfg5
+        a.chains = 16
+        x = synth_cfg5(a.draws, 16, a.params, torch.device("cuda", 0), 55).permute(2, 1, 0)
+        ids = np.repeat(np.arange(1, 5), 4)
+        call = lambda **kw: pkg.rhat_nested(x, ids, kind="rank")  # (synchronous: the entry point has no sync switch)
+    else:
+        x = synth(a.draws, a.chains, a.params, torch.device("cuda", 0), 1234).permute(2, 1, 0)
+        call = lambda **kw: pkg.bulk_tail(x, **kw)
+    call()
     lib, h = pkg._lib.load(), pkg._lib.ctx(0, torch.cuda.current_stream().cuda_stream)
     buf = (ctypes.c_uint64 * 16)()
     lib.mdt_debug_phase_cycles(h, buf, 1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     for _ in range(a.reps):
-        pkg.bulk_tail(x, sync=False)
+        call(sync=False)
     ev1.record()
     torch.cuda.synchronize()
     rc = lib.mdt_debug_phase_cycles(h, buf, 1)
