@@ -441,7 +441,6 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // more split chains than the LDS moment tables hold (many short chains, what nested R-hat is for): every kind runs
     // with one thread per split chain (many_phase), its moments in the scratch of the sorted copy
     const bool many = m > mdt_big::MAXM;
-    if (many && 2 * m > n) return fail(ctx, MDT_EUNSUPPORTED, "chains*split_chains > 256 needs at least 2*split_chains draws");
     if (maxlag > mdt_big::MAXLAG_CAP) return fail(ctx, MDT_EUNSUPPORTED, "effective maxlag > 1000 is not supported");
     if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
     const bool indicators = rq.need_et || rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE;
@@ -504,7 +503,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     }
 
     const long long wgs = tiny ? 2LL * ctx->grid : (small ? ctx->grid : ctx->grid / 2);
-    int rc = ensure_scratch(ctx, n, wgs);
+    int rc = ensure_scratch(ctx, (many && 2 * m > n) ? 2 * m : n, wgs); // (many split chains: their 2 m moments live in the scratch of the sorted copy)
     if (rc) return rc;
     if (strided) {
         const long long need = wgs * ctx->n_pad;

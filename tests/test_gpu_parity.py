@@ -848,6 +848,26 @@ def test_ess_many_chains(pkg, methods):
     S, R = [host(o) for o in pkg.ess_rhat(dev(x))]
     assert np.all(np.isnan(S))
     assert_close(R, co.ess_rhat(x)[1], RTOL64, "rhat with too few draws for ESS")
+    # hardly any draws (down to one per split chain: the 2 m moments then need more scratch than the slice), NaN, Inf, constant
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for D in (1, 2, 3, 4, 5, 6, 11):
+            for s in (1, 2, 3):
+                x = rng.standard_normal((D, 300, 2))
+                for kind in KINDS:
+                    got = [host(o) for o in pkg.ess_rhat(dev(x), kind=kind, split_chains=s)]
+                    want = co.ess_rhat(x, kind=kind, split_chains=s)
+                    assert_close(got[0], want[0], RTOL64, f"ess D={D} s={s} {kind}")
+                    assert_close(got[1], want[1], RTOL64, f"rhat D={D} s={s} {kind}")
+        x = rng.standard_normal((30, 400, 3))
+        x[3, 7, 0] = np.nan
+        x[5, 9, 1] = np.inf
+        x[:, :, 2] = 2.0
+        for kind in KINDS:
+            got = [host(o) for o in pkg.ess_rhat(dev(x), kind=kind)]
+            want = co.ess_rhat(x, kind=kind)
+            assert_close(got[0], want[0], RTOL64, f"ess nan/inf/const {kind}")
+            assert_close(got[1], want[1], RTOL64, f"rhat nan/inf/const {kind}")
 
 
 def test_rhat_nested_permutation_invariance_bitwise(pkg):
