@@ -855,8 +855,13 @@ def test_ess_many_chains(pkg, methods):
             for s in (1, 2, 3):
                 x = rng.standard_normal((D, 300, 2))
                 for kind in KINDS:
+                    try:
+                        want = co.ess_rhat(x, kind=kind, split_chains=s)
+                    except co.OracleError:  # (e.g. more splits than draws)
+                        with pytest.raises((pkg.ArgumentError, pkg.DomainError, pkg.DimensionMismatch)):
+                            pkg.ess_rhat(dev(x), kind=kind, split_chains=s)
+                        continue
                     got = [host(o) for o in pkg.ess_rhat(dev(x), kind=kind, split_chains=s)]
-                    want = co.ess_rhat(x, kind=kind, split_chains=s)
                     assert_close(got[0], want[0], RTOL64, f"ess D={D} s={s} {kind}")
                     assert_close(got[1], want[1], RTOL64, f"rhat D={D} s={s} {kind}")
         x = rng.standard_normal((30, 400, 3))
@@ -864,8 +869,15 @@ def test_ess_many_chains(pkg, methods):
         x[5, 9, 1] = np.inf
         x[:, :, 2] = 2.0
         for kind in KINDS:
-            got = [host(o) for o in pkg.ess_rhat(dev(x), kind=kind)]
-            want = co.ess_rhat(x, kind=kind)
+            try:
+                want = co.ess_rhat(x, kind=kind)
+            except co.OracleError:  # Statistics.quantile throws on NaN (tail ESS)
+                with pytest.raises(pkg.ArgumentError):
+                    pkg.ess_rhat(dev(x), kind=kind)
+                want = co.ess_rhat(x[:, :, 1:], kind=kind)
+                got = [host(o) for o in pkg.ess_rhat(dev(x[:, :, 1:]), kind=kind)]
+            else:
+                got = [host(o) for o in pkg.ess_rhat(dev(x), kind=kind)]
             assert_close(got[0], want[0], RTOL64, f"ess nan/inf/const {kind}")
             assert_close(got[1], want[1], RTOL64, f"rhat nan/inf/const {kind}")
 
