@@ -17,7 +17,7 @@ module MCMCDiagnosticToolsROC
 
 using Statistics: Statistics
 
-export ess, rhat, ess_rhat, rhat_nested, mcse, bfmi, gelmandiag, status
+export ess, rhat, ess_rhat, rhat_nested, mcse, bfmi, gelmandiag, status, UnsupportedOnDevice
 export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
 
 const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")
@@ -85,13 +85,23 @@ function status(; devices=nothing, clear::Bool=true)
     return f[]
 end
 
+"""    UnsupportedOnDevice(msg)
+
+A valid request outside the engine's limits (MDT_EUNSUPPORTED; DESIGN.md §7: effective `maxlag > 1000`, slices beyond
+the ranking's round tables).  Never an approximation: a caller that wants every request of the reference served can
+catch it and hand the request to MCMCDiagnosticTools.jl on the host (INTEGRATION.md)."""
+struct UnsupportedOnDevice <: Exception
+    msg::String
+end
+Base.showerror(io::IO, e::UnsupportedOnDevice) = print(io, "unsupported on the device path: ", e.msg)
+
 function _check(rc::Cint)
     rc == 0 && return nothing
     msg = unsafe_string(ccall((:mdt_last_error, libmdt), Cstring, (Ptr{Cvoid},), ctx()))
     rc == 1 && throw(ArgumentError(msg))
     rc == 2 && throw(DomainError(0, msg))
     rc == 3 && throw(DimensionMismatch(msg))
-    rc == 6 && throw(ArgumentError("unsupported on the device path: " * msg))
+    rc == 6 && throw(UnsupportedOnDevice(msg))
     error("libmdt_hip status $rc: $msg")
 end
 
