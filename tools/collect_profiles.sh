@@ -4,7 +4,7 @@
 # usage (inside gpurun): bash tools/collect_profiles.sh <tag>      then, back home: python tools/summarize_profiles.py <tag>
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
 O=$R/gpurun_out/$TAG; mkdir -p $O
-cd $R && python bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err
+cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 MDT_PROF=1 python tools/phase_profile.py --params 10000 > $O/phase_cfg2.txt 2>/dev/null
 MDT_PROF=1 python tools/phase_profile.py --params 1000 --draws 100000 --chains 8 > $O/phase_cfg3.txt 2>/dev/null
 [ -f tools/exp/libprofq.so ] && MDT_LIB=$R/tools/exp/libprofq.so MDT_PROF=1 python tools/phase_profile.py --params 10000 --q > $O/phase_cfg2_rank.txt 2>/dev/null
@@ -12,7 +12,7 @@ MDT_PROF=1 python tools/phase_profile.py --params 1000 --draws 100000 --chains 8
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
 for cfg in cfg2:10000 cfg3:1000 cfg5:12500; do
   c=${cfg%%:*}; p=${cfg##*:}
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_$c -- python3 $R/tools/run_once.py $p 2 $c > /dev/null 2>&1

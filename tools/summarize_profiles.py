@@ -11,6 +11,30 @@ for f in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
         for row in csv.reader(fi):
             row[0] = row[0][:100]
             w.writerow(row)
+# per-dispatch durations of the engine's kernels in the profiled bench run, in launch order (the first steps + warmup
+# dispatches of mdt_small::mdt_kernel<double> are the headline's; rocprofv3's own avg above includes the cold first call)
+tr = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
+if tr:
+    disp = {}
+    for r in csv.DictReader(open(tr[0])):
+        if "mdt_kernel" in r["Kernel_Name"]:
+            disp.setdefault(r["Kernel_Name"][:60], []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+    try:
+        under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+    except Exception:
+        under = None
+    with open(f"profiles/{tag}_kernel_dispatches.txt", "w") as fo:
+        sw = f"--steps {under['steps']} --warmup {under['warmup']} " if under else ""
+        fo.write(f"# rocprofv3 --kernel-trace of `python3 bench.py {sw}--no-cpu-baseline`: duration of every dispatch, ms, in launch order\n")
+        if under:
+            fo.write(f"# the same run's own line: ms_per_step {under['ms_per_step']:.3f}, roofline.kernel_ms (HIP events) {under['roofline']['kernel_ms']:.3f}\n")
+        for k, v in disp.items():
+            d = [x[1] for x in sorted(v)]
+            fo.write(f"{k}: n={len(d)} mean={sum(d) / len(d):.3f} min={min(d):.3f} max={max(d):.3f}\n  " + " ".join(f"{x:.2f}" for x in d) + "\n")
+            if "small" in k and "double" in k and under and len(d) >= under["steps"] + under["warmup"]:
+                w0 = under["warmup"]
+                t = d[w0:w0 + under["steps"]]
+                fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)}): mean {sum(t) / len(t):.3f} ms\n")
 for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "strided", "kinds"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p) and os.path.getsize(p):
