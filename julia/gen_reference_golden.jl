@@ -12,9 +12,13 @@
 # reference's answers under the same keys the fixture uses:
 #   ess|kind|method|split|maxlag, rhat|...      ess_rhat(x; kind, autocov_method, split_chains, maxlag)   src/ess_rhat.jl:438-624
 #   nested|kind|split, mcse_mean                rhat_nested / mcse                                         src/rhat_nested.jl:43-125, src/mcse.jl:40-51
-#   est|estimator|p|method|split, mcse|...      ess(x; kind = f) / mcse(x; kind = f)                       src/ess_rhat.jl:291-297, src/mcse.jl:52-118
-#   gelman|alpha|psrf(ci), bfmi                 gelmandiag / bfmi                                          src/gelmandiag.jl:76-80, src/bfmi.jl:38-45
-#   stage_rank, stage_z, stage_fold             StatsBase.tiedrank, _rank_normalize, _fold_around_median   src/utils.jl:148-193
+#   essF|..., rhatF|...                         the same calls (Float32 fixtures: the reference computes in Float32 -- the "faithful" keys)
+#   bulk_tail_fft                               [ess bulk; ess tail; rhat bulk; rhat tail] with FFTAutocovMethod, 4 x params
+#   est|estimator|p|method|split, err|est|...   ess(x; kind = f); err|... = the fixture expects the call to throw               src/ess_rhat.jl:291-297
+#   mcse_std, mcseq|estimator|p                 mcse(x; kind = std) / mcse(x; kind = median | Fix2(quantile, p))                 src/mcse.jl:52-118
+#   gelman|alpha|psrf(ci), bfmi                 gelmandiag / bfmi over all chains x params columns         src/gelmandiag.jl:76-80, src/bfmi.jl:38-45
+#   stage_rank[0|1], stage_z, stage_fold, stage_q05   StatsBase.tiedrank, _rank_normalize, _fold_around_median, quantile   src/utils.jl:148-193
+# Not written (no exported counterpart): stage_acov_* (the per-lag mean_autocov of the internal caches), inds, x.
 # Keys whose call throws in the reference (e.g. quantile of data with NaN) are written as a 1-element array holding
 # the sentinel -12345.0 so the comparison can check that the device path refuses them too.
 using MCMCDiagnosticTools, NPZ, Statistics, StatsBase
@@ -55,18 +59,32 @@ function reference_answers(name::AbstractString, d::Dict)
             out[key] = arr(guard(() -> rhat_nested(x, ids; kind=Symbol(parts[2]), split_chains=parse(Int, parts[3]))))
         elseif key == "mcse_mean"
             out[key] = arr(guard(() -> mcse(x)))
-        elseif parts[1] == "est" && length(parts) == 5
-            f = estimator(parts[2], parse(Float64, parts[3]))
-            out[key] = arr(guard(() -> ess(x; kind=f, autocov_method=METHODS[parts[4]], split_chains=parse(Int, parts[5]))))
-        elseif parts[1] == "mcse" && length(parts) >= 3
+        elseif (parts[1] == "essF" || parts[1] == "rhatF") && length(parts) == 5
+            kind, m, s, ml = Symbol(parts[2]), METHODS[parts[3]], parse(Int, parts[4]), parse(Int, parts[5])
+            r = guard(() -> ess_rhat(x; kind, autocov_method=m, split_chains=s, maxlag=ml))
+            out[key] = r === THREW ? THREW : arr(parts[1] == "essF" ? r.ess : r.rhat)
+        elseif key == "bulk_tail_fft"
+            b = guard(() -> ess_rhat(x; kind=:bulk, autocov_method=FFTAutocovMethod()))
+            t = guard(() -> ess_rhat(x; kind=:tail, autocov_method=FFTAutocovMethod()))
+            out[key] = (b === THREW || t === THREW) ? THREW : permutedims(hcat(arr(b.ess), arr(t.ess), arr(b.rhat), arr(t.rhat)))  # 4 x params
+        elseif (parts[1] == "est" && length(parts) == 5) || (parts[1] == "err" && length(parts) == 6 && parts[2] == "est")
+            q = parts[1] == "est" ? parts[2:end] : parts[3:end]
+            f = estimator(q[1], parse(Float64, q[2]))
+            out[key] = arr(guard(() -> ess(x; kind=f, autocov_method=METHODS[q[3]], split_chains=parse(Int, q[4]))))
+        elseif key == "mcse_std"
+            out[key] = arr(guard(() -> mcse(x; kind=Statistics.std)))
+        elseif parts[1] == "mcseq" && length(parts) == 3
             f = estimator(parts[2], parse(Float64, parts[3]))
             out[key] = arr(guard(() -> mcse(x; kind=f)))
         elseif parts[1] == "gelman" && length(parts) == 3
             g = guard(() -> gelmandiag(x; alpha=parse(Float64, parts[2])))
             out[key] = g === THREW ? THREW : arr(getproperty(g, Symbol(parts[3])))
         elseif key == "bfmi"
-            out[key] = arr(guard(() -> bfmi(x[:, :, 1])))
+            out[key] = arr(guard(() -> bfmi(reshape(x, size(x, 1), :))))   # one value per (chain, param) column
         end
+    end
+    for (key, ip) in (("stage_rank0", 1), ("stage_rank1", 2))
+        haskey(d, key) && (out[key] = reshape(StatsBase.tiedrank(vec(x[:, :, ip])), size(x[:, :, ip])))
     end
     if haskey(d, "stage_rank")                     # the third-party boundaries, parameter 1
         xp = x[:, :, 1]

@@ -3,6 +3,7 @@
 There is no CPU fallback: if the shared library is missing or no GPU is visible, every compute
 entry point raises.  Build with `python -c "import __graft_entry__ as g; g.build()"`.
 """
+import contextlib
 import ctypes
 import os
 import threading
@@ -98,60 +99,104 @@ def load():
     return _lib
 
 
+class _Entry:
+    """a registered context: handle, its lock (an mdt_ctx is single-owner) and the number of calls that hold it"""
+    __slots__ = ("h", "lock", "pins")
+
+    def __init__(self, h):
+        self.h, self.lock, self.pins = h, threading.Lock(), 0
+
+
 _ctxs = {}
-_locks = {}
 _ctxs_lock = threading.Lock()
 MAX_CTX_PER_DEVICE = 4  # every context owns ~0.5 GB of per-workgroup scratch at the config-2 slice size
 FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = 1, 2, 4
 
 
-def ctx(device, stream=None):
-    """One mdt_ctx per (GPU, stream) per process.  A context owns the scratch its kernels work in, so requests that
-    may run concurrently -- different streams -- must not share one; requests on one stream are ordered and do.
-    At most MAX_CTX_PER_DEVICE live per GPU: the least recently created one (never the default stream's) is
-    destroyed first (mdt_ctx_destroy synchronises the device).  `device` may be a tuple of device ordinals: one
-    multi-GPU context (mdt_ctx_create_multi) per tuple."""
-    lib = load()
+def _key(device, stream):
     multi = isinstance(device, (tuple, list))
-    key = (tuple(int(d) for d in device), 0) if multi else (int(device), int(stream or 0))
+    return (tuple(int(d) for d in device), 0) if multi else (int(device), int(stream or 0))
+
+
+def _entry(key):
+    """the registered context of `key`, created on first use.  Caller holds _ctxs_lock.
+    At most MAX_CTX_PER_DEVICE live per GPU; beyond that one that nobody holds (pins == 0), that is not the default
+    stream's and that has no unread sticky flags (what sync=False requests could not report) is destroyed first --
+    mdt_ctx_status waits for its queued work, mdt_ctx_destroy synchronises the device.  When every candidate is held
+    or has flags to report, nothing is evicted and the cap is exceeded."""
+    lib = load()
+    e = _ctxs.get(key)
+    if e is not None:
+        return e
+    h = ctypes.c_void_p()
+    if isinstance(key[0], tuple):
+        ids = (ctypes.c_int * len(key[0]))(*key[0])
+        rc = lib.mdt_ctx_create_multi(ctypes.byref(h), ids, len(key[0]))
+    else:
+        mine = [k for k in _ctxs if k[0] == key[0]]
+        if len(mine) >= MAX_CTX_PER_DEVICE:
+            for victim in mine:
+                ve = _ctxs[victim]
+                if victim[1] == 0 or ve.pins != 0:
+                    continue
+                f = ctypes.c_int32(0)
+                with ve.lock:  # (pins == 0 under _ctxs_lock: nobody is inside the library with it, nobody can get it)
+                    rcs = lib.mdt_ctx_status(ve.h, ctypes.byref(f), 0)
+                    if rcs == MDT_OK and f.value == 0:
+                        del _ctxs[victim]
+                        lib.mdt_ctx_destroy(ve.h)
+                        break
+        rc = lib.mdt_ctx_create(ctypes.byref(h), key[0])
+    if rc != MDT_OK:
+        raise MdtRuntimeError(f"mdt_ctx_create(device={key[0]}) failed with status {rc} "
+                              "(no MI355X visible? there is no CPU fallback)")
+    e = _Entry(h)
+    _ctxs[key] = e
+    return e
+
+
+@contextlib.contextmanager
+def using(device, stream=None):
+    """`with using(device, stream) as h:` -- the context of (GPU, stream) (or of a tuple of GPUs: one multi-GPU context
+    per tuple), held for the duration of the block: it cannot be evicted while held, and the block runs under the
+    context's lock (ctypes releases the GIL during a call, so two Python threads on the same (device, stream) must not
+    enter the library together)."""
+    key = _key(device, stream)
     with _ctxs_lock:
-        if key not in _ctxs:
-            h = ctypes.c_void_p()
-            if multi:
-                ids = (ctypes.c_int * len(key[0]))(*key[0])
-                rc = lib.mdt_ctx_create_multi(ctypes.byref(h), ids, len(key[0]))
-            else:
-                mine = [k for k in _ctxs if k[0] == key[0]]
-                if len(mine) >= MAX_CTX_PER_DEVICE:
-                    victim = next(k for k in mine if k[1] != 0)
-                    with _locks[victim]:
-                        lib.mdt_ctx_destroy(_ctxs.pop(victim))
-                    del _locks[victim]
-                rc = lib.mdt_ctx_create(ctypes.byref(h), int(device))
-            if rc != MDT_OK:
-                raise MdtRuntimeError(f"mdt_ctx_create(device={device}) failed with status {rc} "
-                                      "(no MI355X visible? there is no CPU fallback)")
-            _ctxs[key] = h
-            _locks[key] = threading.Lock()
-        return _ctxs[key]
+        e = _entry(key)
+        e.pins += 1
+    try:
+        with e.lock:
+            yield e.h
+    finally:
+        with _ctxs_lock:
+            e.pins -= 1
+
+
+def ctx(device, stream=None):
+    """The raw handle of the context of (GPU, stream) -- diagnostics and tests; calls go through `using`, which also
+    protects the handle against eviction.  One mdt_ctx per (GPU, stream) per process: a context owns the scratch its
+    kernels work in, so requests that may run concurrently -- different streams -- must not share one."""
+    with _ctxs_lock:
+        return _entry(_key(device, stream)).h
 
 
 def lock(h):
-    """the lock of a context: an mdt_ctx is single-owner (include/mdt_hip.h), ctypes releases the GIL during a call,
-    so two Python threads on the same (device, stream) must not enter the library together"""
+    """the lock of a registered context (diagnostics; `using` takes it itself).  A handle that is no longer
+    registered was destroyed: using it would be a use-after-free, so this raises instead of inventing a lock."""
     with _ctxs_lock:
-        for k, v in _ctxs.items():
-            if v.value == h.value:
-                return _locks[k]
-    return threading.Lock()
+        for e in _ctxs.values():
+            if e.h.value == h.value:
+                return e.lock
+    raise MdtRuntimeError("this mdt_ctx handle is no longer registered (it was evicted and destroyed)")
 
 
-def status(h, clear=True):
-    """sticky condition flags of the context (mdt_ctx_status): what asynchronous requests could not report"""
+def status(key, clear=True):
+    """sticky condition flags of the context of key = (device, stream) (mdt_ctx_status): what asynchronous requests
+    could not report"""
     f = ctypes.c_int32(0)
-    with lock(h):
-        rc = load().mdt_ctx_status(h, ctypes.byref(f), 1 if clear else 0)
-    check(rc, h)
+    with using(*key) as h:
+        check(load().mdt_ctx_status(h, ctypes.byref(f), 1 if clear else 0), h)
     return int(f.value)
 
 

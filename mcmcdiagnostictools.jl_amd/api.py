@@ -101,7 +101,11 @@ class _Prepared:
     pass
 
 
-def _prepare(samples):
+def _prepare(samples, allow_strided=False):
+    """allow_strided: a CUDA tensor whose draws are contiguous but whose chains / parameters are strided is handed
+    over in place (chain_stride / param_stride of mdt_args) instead of being copied dense.  Only the entry points that
+    go through the library's run() read those strides; everything else (bfmi, gelmandiag, the stage output, a
+    multi-GPU context) gets the dense copy."""
     pr = _Prepared()
     mask = None
     if isinstance(samples, np.ma.MaskedArray):  # the reference's Union{Missing,T} eltype
@@ -132,7 +136,7 @@ def _prepare(samples):
     if is_torch:
         st = x3.stride() if D * C * P > 0 else (1, D, D * C)
         dense = (st[0] == 1 or D == 1) and (st[1] == D or C == 1) and (st[2] == D * C or P == 1)
-        if x3.is_cuda and not dense and (st[0] == 1 or D == 1) and (st[1] >= D or C == 1) and (st[2] >= 1 or P == 1):
+        if allow_strided and x3.is_cuda and not dense and (st[0] == 1 or D == 1) and (st[1] >= D or C == 1) and (st[2] >= 1 or P == 1):
             # draws contiguous, chains / parameters strided (e.g. MCMCChains' (iterations, parameters, chains)
             # storage viewed as (draws, chains, params)): read in place through the strides of mdt_args
             pr.cs = int(st[1]) if C > 1 else D
@@ -187,20 +191,20 @@ def _args(pr, kind, outputs, autocov, split_chains, maxlag, relative, tail_prob,
                         getattr(pr, "cs", 0), getattr(pr, "ps", 0))
 
 
-def _ctx(pr, devices=None):
-    """the context of (device, current stream): concurrent streams never share scratch.  `devices`: a sequence of
-    GPU ordinals -> the multi-GPU context over them (params axis cut into contiguous blocks, mdt_ctx_create_multi)"""
+def _ctx_key(pr, devices=None):
+    """(device, stream) of the context a request runs on: concurrent streams never share scratch.  `devices`: a sequence
+    of GPU ordinals -> the multi-GPU context over them (params axis cut into contiguous blocks, mdt_ctx_create_multi)"""
     if devices is not None:
-        return _lib.ctx(tuple(int(d) for d in devices))
+        return tuple(int(d) for d in devices), None
     stream = torch.cuda.current_stream(pr.buf.device).cuda_stream if pr.dev else 0
-    return _lib.ctx(pr.device_index if pr.dev else 0, stream)
+    return (pr.device_index if pr.dev else 0), stream
 
 
-def _call(h, fn, *args):
-    """one library call on context h: under the context's lock (an mdt_ctx is single-owner), status -> exception"""
-    with _lib.lock(h):
-        rc = fn(h, *args)
-    _lib.check(rc, h)
+def _call(key, fn, *args):
+    """one library call on the context of `key`: held against eviction and under its lock (an mdt_ctx is single-owner)
+    for the whole call, status -> exception while the context (and its error message) is still held"""
+    with _lib.using(*key) as h:
+        _lib.check(fn(h, *args), h)
 
 
 def status(device=None, *, devices=None, clear=True):
@@ -208,9 +212,9 @@ def status(device=None, *, devices=None, clear=True):
     `devices` -- after waiting for its queued work (mdt_ctx_status): what requests issued with sync=False could not
     raise.  Bits: FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE (the reference throws ArgumentError there), FLAG_FDIST."""
     if devices is not None:
-        return _lib.status(_lib.ctx(tuple(int(d) for d in devices)), clear)
+        return _lib.status((tuple(int(d) for d in devices), None), clear)
     dev = torch.cuda.current_device() if device is None else int(device)
-    return _lib.status(_lib.ctx(dev, torch.cuda.current_stream(dev).cuda_stream), clear)
+    return _lib.status((dev, torch.cuda.current_stream(dev).cuda_stream), clear)
 
 
 FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = _lib.FLAG_RANK_OVERFLOW, _lib.FLAG_NAN_QUANTILE, _lib.FLAG_FDIST
@@ -258,13 +262,13 @@ def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_m
     if split_chains < 1:
         raise ArgumentError("split_chains must be >= 1")
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
-    pr = _prepare(samples)
+    pr = _prepare(samples, allow_strided=devices is None)
     if want_ess:
         _warn_niter(pr, split_chains)
     ess_o = _new_out(pr) if want_ess else None
     rhat_o = _new_out(pr) if want_rhat else None
     if pr.P > 0:
-        h = _ctx(pr, devices)
+        h = _ctx_key(pr, devices)
         a = _args(pr, _lib.KIND[kind], (1 if want_ess else 0) | (2 if want_rhat else 0), autocov, split_chains,
                   maxlag, relative, tail_prob, sync)
         _call(h, _lib.load().mdt_ess_rhat, ctypes.byref(a), pr.ptr, _optr(ess_o), _optr(rhat_o))
@@ -336,13 +340,13 @@ def bulk_tail(samples, *, relative=False, autocov_method=None, split_chains=2, m
     split_chains = _check_int("split_chains", split_chains)
     maxlag = _check_int("maxlag", maxlag)
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
-    pr = _prepare(samples)
+    pr = _prepare(samples, allow_strided=devices is None)
     _warn_niter(pr, split_chains)
     if out is not None:
         _check_out(pr, out)
     outs = out if out is not None else [_new_out(pr) for _ in range(4)]
     if pr.P > 0:
-        h = _ctx(pr, devices)
+        h = _ctx_key(pr, devices)
         a = _args(pr, 0, 3, autocov, split_chains, maxlag, relative, tail_prob, sync)
         _call(h, _lib.load().mdt_bulk_tail, ctypes.byref(a), pr.ptr, *[_optr(o) for o in outs])
     if out is not None:
@@ -377,10 +381,10 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, devices
     kind = _norm_kind(kind)
     if kind not in _KINDS:
         raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat_nested`")
-    pr = _prepare(samples)
+    pr = _prepare(samples, allow_strided=devices is None)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _ctx(pr, devices)
+        h = _ctx_key(pr, devices)
         a = _args(pr, _lib.KIND[kind], 2, 0, split_chains, 250, False, 0.1)
         K, S = inds.shape
         _call(h, _lib.load().mdt_rhat_nested, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(out))
@@ -401,11 +405,11 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     devices = kwargs.pop("devices", None)
     if kwargs:
         raise TypeError(f"unsupported keyword arguments {sorted(kwargs)}")
-    pr = _prepare(samples)
+    pr = _prepare(samples, allow_strided=devices is None)
     _warn_niter(pr, split_chains)
     out = _new_out(pr)
     if pr.P > 0:
-        h = _ctx(pr, devices)
+        h = _ctx_key(pr, devices)
         lib = _lib.load()
         if est is None or est[0] == "std":
             a = _args(pr, 0, 1, autocov, split_chains, maxlag, relative, 0.1)
@@ -425,7 +429,7 @@ def rank_normalize(samples, *, fold=False, want_ranks=True):
     ranks = _new_out(pr, n, (torch.float64 if pr.torch else np.float64)) if want_ranks else None
     z = _new_out(pr, n)
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx_key(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         _call(h, _lib.load().mdt_rank_normalize, ctypes.byref(a), pr.ptr, 1 if fold else 0, _optr(ranks), _optr(z))
 
@@ -454,7 +458,7 @@ def from_mcmcchains_layout(samples):
     pr.f32 = samples.dtype == torch.float32
     pr.dev, pr.buf = True, out
     pr.device_index = samples.device.index or 0
-    h = _ctx(pr)
+    h = _ctx_key(pr)
     a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
     _call(h, _lib.load().mdt_layout_from_dpc, ctypes.byref(a), ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()))
     return out.permute(2, 1, 0)
@@ -484,7 +488,7 @@ def bfmi(energy, *, dims=1):
     pr = _prepare(e2)
     out = _new_out(pr, pr.C)
     if pr.C > 0:
-        h = _ctx(pr)
+        h = _ctx_key(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         _call(h, _lib.load().mdt_bfmi, ctypes.byref(a), pr.ptr, _optr(out))
     return float(out[0]) if e.ndim == 1 else out
@@ -502,7 +506,7 @@ def gelmandiag(samples, *, alpha=0.05):
     f64 = torch.float64 if pr.torch else np.float64
     psrf, ci = _new_out(pr, pr.P, f64), _new_out(pr, pr.P, f64)
     if pr.P > 0:
-        h = _ctx(pr)
+        h = _ctx_key(pr)
         a = _args(pr, 0, 0, 0, 1, 250, False, 0.1)
         _call(h, _lib.load().mdt_gelmandiag, ctypes.byref(a), pr.ptr, float(alpha), _optr(psrf), _optr(ci))
     return GelmanDiag(psrf, ci)

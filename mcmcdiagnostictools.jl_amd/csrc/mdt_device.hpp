@@ -135,6 +135,7 @@ struct KP {
     int est;                    // ess(kind = estimator): 0 none, 4 median, 5 std, 6 mad, 7 quantile(p) (src/ess_rhat.jl:626-659); mode 4: mcse(std)
     int winout;                 // 1: chains that do not fit the LDS take the windowed score layout (series_win_phase); 0: time-order scatter (MDT_WINOUT=0: tests, A/B timing)
     int fold_merge;             // 1: rank |x - median| by merging the sorted slice when the ranking of x left one (fold_merge_phase); 0: always the general ranking (MDT_FOLD_MERGE=0: tests, A/B timing)
+    int pa_on;                  // 1: tile-major partition where it applies (rank_phase_q, `pa`); 0: histogram + partition passes (MDT_PA=0: tests, A/B timing)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
@@ -157,6 +158,8 @@ struct KP {
     int K, S;
     int* status;                // device status words: [0] flags of this launch (bit0 rounds overflow, bit1 NaN hit quantile, bit2 FDist); [1] next-parameter ticket; [2] sticky flags of earlier launches
     unsigned long long* prof;   // optional [grid*16] phase cycle counters (diagnostics), or null
+    const unsigned int* order;  // ticket t works on parameter order[t] (costliest first, by the durations the previous launch of the same shape measured), or null: t itself
+    unsigned int* cost;         // [P] duration of every parameter of this launch (shader clocks >> 6), for the next launch's order; or null
 };
 } // namespace mdtc
 #endif
@@ -495,12 +498,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
     // parameters are handed out dynamically (one atomic ticket per parameter): slowly mixing
     // parameters need more lag blocks than well-mixed ones, and a static stride leaves CUs idle
     int* tick = (int*)(smem + OFF_INTS) + 11;
+    // The persistent launch ends with a tail in which the workgroups run out of tickets one after the other; it is
+    // shortest when the costly parameters went first.  Every launch therefore leaves the duration of each parameter
+    // (kp.cost), an epilogue kernel sorts them (order_kernel), and the next launch of the same shape hands its tickets out
+    // in that order (kp.order): requests repeated on the same chains -- monitoring a run, the bench -- start with the
+    // slowly mixing parameters.  The order never changes a result (every parameter is computed independently).
+    long long t_prev = 0, p_prev = -1;
     while (true) {
-        if (tid == 0) *tick = atomicAdd(kp.status + 1, 1);
+        if (tid == 0) {
+            if (kp.cost) {
+                const long long now = clock64();
+                if (p_prev >= 0) kp.cost[p_prev] = (unsigned)((unsigned long long)(now - t_prev) >> 6);
+                t_prev = now;
+            }
+            *tick = atomicAdd(kp.status + 1, 1);
+        }
         __syncthreads();
-        const long long p = (long long)uni(*tick); // wave-uniform: every branch on p is a scalar branch
+        const long long tk = (long long)uni(*tick); // wave-uniform: every branch on it is a scalar branch
         __syncthreads();
-        if (p >= kp.P) break;
+        if (tk >= kp.P) break;
+        long long p = tk;
+        if (kp.order) { // (a vector load made uniform: the scalar cache may hold a stale line of the table)
+            int zero = 0;
+            asm volatile("" : "+v"(zero));
+            p = (long long)(unsigned)uni((int)kp.order[tk + zero]);
+        }
+        p_prev = p;
         const T* xp = (const T*)kp.x + p * (kp.strided ? kp.pstride : n);
         if (kp.strided) {
             // x[d + cstride * c + pstride * p] (e.g. MCMCChains' (iterations, parameters, chains) storage, read in place):

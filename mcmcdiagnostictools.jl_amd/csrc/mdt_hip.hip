@@ -87,6 +87,13 @@ struct mdt_ctx {
     // status words (flags of the launch, ticket, sticky flags) + nested chain indices
     int* status = nullptr;
     unsigned long long* prof = nullptr; // [2*grid*16] phase cycle counters when MDT_PROF is set
+    // ticket order of the persistent launch: cost[p] = duration of parameter p in the last launch, order = parameters by
+    // decreasing cost (order_kernel, queued behind every launch); used by the next launch with the same number of parameters
+    unsigned int* cost = nullptr;
+    unsigned int* order = nullptr;
+    unsigned int* order_sorted = nullptr; // work area of order_kernel: the parameters by decreasing cost
+    long long order_cap = 0;
+    long long order_P = -1;             // the order on the device is a permutation of [0, order_P); -1: none
     KP* kp_ring = nullptr;              // device copies of the kernel parameters, one slot per launch
     unsigned kp_next = 0;
     int* chain_inds = nullptr;
@@ -302,6 +309,41 @@ __global__ void kp_setup_kernel(KP* slot, KP v, int* status, int keep_status) {
 // the same bookkeeping for the entry points that do not go through mdt_kernel (gelmandiag)
 __global__ void status_begin_kernel(int* status) {
     if (threadIdx.x == 0) { status[2] |= status[0]; status[0] = 0; status[1] = 0; }
+}
+
+// Parameters by decreasing cost: a counting sort over ORDER_BINS linear cost classes by one workgroup (three passes over
+// the costs; P = 10 000: ~10 us, queued BEHIND the launch that measured them).  Inside a class the order is whatever the
+// atomics give -- any permutation is a valid ticket order.  Only the END of the ticket sequence has to be sorted (the
+// cheapest `tail` parameters, costliest of them first: that is what shortens the tail of the launch); the tickets before
+// it are dealt in a strided walk over the sorted sequence instead, so that neighbouring tickets differ in cost: workgroups
+// that all work on equally costly parameters stay in lockstep -- every CU in the same phase at the same time, all of them
+// on HBM or all of them on the LDS -- and lose what two workgroups per CU are there for.
+constexpr int ORDER_BINS = 1024;
+__global__ __launch_bounds__(1024) void order_kernel(const unsigned int* __restrict__ cost, unsigned int* __restrict__ sorted,
+                                                     unsigned int* __restrict__ order, long long P, long long tail, long long stride) {
+    __shared__ unsigned cmax, lh[ORDER_BINS + 1];
+    const int tid = threadIdx.x;
+    if (tid == 0) cmax = 0u;
+    for (int b = tid; b <= ORDER_BINS; b += 1024) lh[b] = 0u;
+    __syncthreads();
+    unsigned m = 0u;
+    for (long long i = tid; i < P; i += 1024) m = cost[i] > m ? cost[i] : m;
+    atomicMax(&cmax, m);
+    __syncthreads();
+    const unsigned long long cm = (unsigned long long)cmax + 1ull;
+    // class 0 = the costliest
+    auto cls = [&](unsigned c) -> unsigned { return (unsigned)(ORDER_BINS - 1) - (unsigned)(((unsigned long long)c * ORDER_BINS) / cm); };
+    for (long long i = tid; i < P; i += 1024) atomicAdd(&lh[cls(cost[i])], 1u);
+    __syncthreads();
+    if (tid == 0) {
+        unsigned run = 0u;
+        for (int b = 0; b < ORDER_BINS; ++b) { const unsigned c = lh[b]; lh[b] = run; run += c; }
+    }
+    __syncthreads();
+    for (long long i = tid; i < P; i += 1024) sorted[atomicAdd(&lh[cls(cost[i])], 1u)] = (unsigned)i;
+    __syncthreads(); // (one workgroup: its own global stores are visible to it after the barrier)
+    const long long head = P - tail; // stride is coprime with head: i -> i * stride mod head is a permutation
+    for (long long i = tid; i < P; i += 1024) order[i] = (i < head) ? sorted[(unsigned long long)i * (unsigned long long)stride % (unsigned long long)head] : sorted[i];
 }
 
 constexpr unsigned KP_RING = 64;
@@ -593,6 +635,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     }
     { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
     { const char* wo = getenv("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
+    { const char* pe = getenv("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
@@ -600,6 +643,24 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.tpos_arr = rq.tpos_arr;
     kp.status = ctx->status;
     kp.prof = ctx->prof;
+    // ticket order: by the durations the previous launch with as many parameters measured; this launch measures again
+    kp.order = nullptr; kp.cost = nullptr;
+    const bool lpt = P >= 4 * wgs && P < 0xFFFFFFFFLL && !getenv("MDT_NO_ORDER"); // (fewer tickets than that: there is no tail to speak of)
+    if (lpt) {
+        if (P > ctx->order_cap) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->cost) (void)hipFree(ctx->cost);
+            if (ctx->order) (void)hipFree(ctx->order);
+            if (ctx->order_sorted) (void)hipFree(ctx->order_sorted);
+            ctx->cost = nullptr; ctx->order = nullptr; ctx->order_sorted = nullptr; ctx->order_cap = 0; ctx->order_P = -1;
+            HIP_TRY(hipMalloc((void**)&ctx->cost, (size_t)P * sizeof(unsigned int)));
+            HIP_TRY(hipMalloc((void**)&ctx->order, (size_t)P * sizeof(unsigned int)));
+            HIP_TRY(hipMalloc((void**)&ctx->order_sorted, (size_t)P * sizeof(unsigned int)));
+            ctx->order_cap = P;
+        }
+        kp.cost = ctx->cost;
+        if (ctx->order_P == P) kp.order = ctx->order;
+    }
 
     const unsigned grid = (unsigned)((P < wgs) ? P : wgs);
     void (*kern)(const KP*) = tiny ? (f32 ? mdt_tiny::mdt_kernel<float> : mdt_tiny::mdt_kernel<double>)
@@ -613,6 +674,18 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     KP* slot = ctx->kp_ring + si;
     hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
+    if (lpt) { // (same stream: it runs when every duration is in, and before the next launch reads the order)
+        // the cheapest 2 x wgs parameters close the launch in sorted order; the others are walked with a stride near head / 7.3
+        long long tail = std::min<long long>(P, 2 * wgs), head = P - tail, stride = 1;
+        if (const char* e = getenv("MDT_ORDER_TAIL")) { tail = std::min<long long>(P, std::max<long long>(0, atoll(e))); head = P - tail; } // (A/B timing)
+        if (head > 2 && !getenv("MDT_ORDER_PURE")) {
+            stride = std::max<long long>(2, (long long)((double)head / 7.3));
+            auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
+            while (gcd(stride, head) != 1) ++stride;
+        }
+        hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, (const unsigned int*)ctx->cost, ctx->order_sorted, ctx->order, P, tail, stride);
+        ctx->order_P = P;
+    }
     HIP_TRY(hipGetLastError());
     ctx->last_stream = st;
     ctx->used = true;
@@ -784,6 +857,9 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->mom) (void)hipFree(ctx->mom);
     if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
     if (ctx->ibits) (void)hipFree(ctx->ibits);
+    if (ctx->cost) (void)hipFree(ctx->cost);
+    if (ctx->order) (void)hipFree(ctx->order);
+    if (ctx->order_sorted) (void)hipFree(ctx->order_sorted);
     delete ctx;
     return MDT_OK;
 }
@@ -963,8 +1039,11 @@ int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse
     a1.location = MDT_DEVICE;
     a1.sync = 0;
     const void* dx = x;
-    if (a->location == MDT_HOST) { // stage x once for both passes
-        const size_t xb = (size_t)n * P * ts;
+    if (a->location == MDT_HOST) { // stage x once for both passes: its whole extent, whatever lies between its pieces (as run() does)
+        const long long cs = a->chain_stride ? a->chain_stride : a->draws, ps = a->param_stride ? a->param_stride : n;
+        if (cs < a->draws || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
+        if (a->draws <= 0 || a->chains <= 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+        const size_t xb = (size_t)((P - 1) * ps + (a->chains - 1) * cs + a->draws) * ts;
         if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
@@ -1006,6 +1085,7 @@ int mdt_layout_from_dpc(mdt_ctx* ctx, const mdt_args* a, const void* x_dpc, void
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
     if (x_dpc == x_dcp) return fail(ctx, MDT_EARG, "the permutation is out of place");
+    if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "mdt_layout_from_dpc takes dense buffers (chain_stride = param_stride = 0)");
     const long long runs = a->chains * a->params;
     if (runs == 0 || a->draws == 0) return MDT_OK;
     if (runs > 2147483647LL) return fail(ctx, MDT_EUNSUPPORTED, "chains*params too large");
@@ -1058,6 +1138,8 @@ static int diag_args_ok(mdt_ctx* ctx, const mdt_args* a) {
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
     if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    // the column pass reads x as dense (draws, chains, params): a strided request would mix chains and parameters silently
+    if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "this entry point takes the dense layout only (chain_stride = param_stride = 0)");
     return MDT_OK;
 }
 

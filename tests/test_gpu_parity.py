@@ -413,6 +413,131 @@ def test_mcmcchains_storage_order(pkg):
             assert np.array_equal(host(c.ess), host(b.ess)) and np.array_equal(host(c.rhat), host(b.rhat))
 
 
+def test_strided_views_of_dense_only_entry_points(pkg):
+    """gelmandiag / bfmi read x as dense (draws, chains, params): a permuted or sliced view is copied dense by the host
+    mirror (never handed over with strides), the C-ABI itself refuses strides there, and a strided view together with
+    `devices=` takes the dense path too.  Round-2 advisor findings."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(19)
+    shape = (400, 4, 6)
+    x = (ar1(0.5, *shape, rng) + 0.1 * rng.standard_normal(shape))
+    store = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 2, 0)))).cuda()   # MCMCChains storage
+    view = store.permute(2, 0, 1)                                                       # strides (1, D*P, D)
+    assert view.stride() == (1, shape[0] * shape[2], shape[0])
+    g_view, g_dense = pkg.gelmandiag(view), pkg.gelmandiag(dev(x))
+    assert np.array_equal(host(g_view.psrf), host(g_dense.psrf)) and np.array_equal(host(g_view.psrfci), host(g_dense.psrfci))
+    from oracle import c_oracle
+    want = c_oracle.gelmandiag(x)
+    assert_close(host(g_view.psrf), want[0], 1e-9)
+    e = torch.from_numpy(rng.standard_normal((500, 8))).cuda()                          # (draws, chains), C-order: draws strided
+    sl = e[:, ::2]
+    assert np.array_equal(host(pkg.bfmi(sl)), host(pkg.bfmi(sl.contiguous())))
+    assert_close(host(pkg.bfmi(sl)), c_oracle.bfmi(sl.cpu().numpy()), 1e-9)
+    # devices= with a strided view: dense copy, same bits as the single context
+    r1 = pkg.rhat(view, devices=[0])
+    assert np.array_equal(host(r1), host(pkg.rhat(dev(x))))
+    # the C-ABI refuses strides where the kernels would ignore them
+    lib = pkg._lib.load()
+    xd = dev(x).permute(2, 1, 0).contiguous()
+    out = torch.empty(shape[2], dtype=torch.float64, device="cuda")
+    out2 = torch.empty_like(out)
+    a = pkg._lib.MdtArgs(shape[0], shape[1], shape[2], pkg._lib.MDT_F64, pkg._lib.MDT_DEVICE, 0, 0, 0, 1, 0, 1, 250, 0.1, None,
+                         shape[0] * shape[2], shape[0])
+    with pkg._lib.using(0, 0) as h:
+        assert lib.mdt_gelmandiag(h, ctypes.byref(a), xd.data_ptr(), 0.05, out.data_ptr(), out2.data_ptr()) == pkg._lib.MDT_EARG
+        assert lib.mdt_bfmi(h, ctypes.byref(a), xd.data_ptr(), out.data_ptr()) == pkg._lib.MDT_EARG
+        assert lib.mdt_layout_from_dpc(h, ctypes.byref(a), xd.data_ptr(), out.data_ptr()) == pkg._lib.MDT_EARG
+
+
+def test_mcse_quantile_strided_host_request(pkg):
+    """mdt_mcse_quantile with location = MDT_HOST and strides stages the whole strided extent (it staged the dense
+    size once: an out-of-bounds device read).  Through the raw C-ABI, against the dense host call."""
+    import ctypes
+    rng = np.random.default_rng(23)
+    D, C, P = 600, 3, 5
+    x = ar1(0.4, D, C, P, rng)
+    store = np.ascontiguousarray(np.transpose(x, (1, 2, 0)))       # (chains, params, draws): cs = D*P, ps = D
+    dense = np.ascontiguousarray(np.transpose(x, (2, 1, 0)))       # (params, chains, draws)
+    lib = pkg._lib.load()
+    o1, o2 = np.empty(P), np.empty(P)
+    L = pkg._lib
+    a_s = L.MdtArgs(D, C, P, L.MDT_F64, L.MDT_HOST, L.KIND["median"], 1, 0, 2, 0, 1, 250, 0.5, None, D * P, D)
+    a_d = L.MdtArgs(D, C, P, L.MDT_F64, L.MDT_HOST, L.KIND["median"], 1, 0, 2, 0, 1, 250, 0.5, None, 0, 0)
+    with L.using(0, 0) as h:
+        assert lib.mdt_mcse_quantile(h, ctypes.byref(a_s), store.ctypes.data, o1.ctypes.data) == 0, lib.mdt_last_error(h)
+        assert lib.mdt_mcse_quantile(h, ctypes.byref(a_d), dense.ctypes.data, o2.ctypes.data) == 0, lib.mdt_last_error(h)
+    assert np.array_equal(o1, o2) and np.all(np.isfinite(o1))
+
+
+def test_context_registry_pins_and_never_drops_flags(pkg):
+    """a context in use cannot be evicted, one with unread sticky flags is not evicted either, and a handle that was
+    destroyed is refused instead of being given a fresh lock (round-2 advisor finding on _lib.ctx / lock)"""
+    import torch
+    L = pkg._lib
+    x = dev(np.random.default_rng(5).standard_normal((200, 2, 3)))
+    streams = [torch.cuda.Stream() for _ in range(L.MAX_CTX_PER_DEVICE + 2)]
+    with L.using(0, streams[0].cuda_stream) as h0:
+        for st in streams[1:]:
+            with torch.cuda.stream(st):
+                pkg.rhat(x)
+        assert any(e.h.value == h0.value for e in L._ctxs.values())   # held: survived the evictions
+    gone = None
+    for k, e in list(L._ctxs.items()):
+        if k[0] == 0 and k[1] != 0:
+            gone = e.h
+    for st in [torch.cuda.Stream() for _ in range(L.MAX_CTX_PER_DEVICE)]:
+        with torch.cuda.stream(st):
+            pkg.rhat(x)
+    if gone is not None and not any(e.h.value == gone.value for e in L._ctxs.values()):
+        with pytest.raises(L.MdtRuntimeError):
+            L.lock(gone)
+    torch.cuda.synchronize()
+
+
+def test_tile_major_partition_and_ticket_order_change_no_bit(pkg, monkeypatch):
+    """Round 3: the tile-major partition (one pass instead of histogram + partition, MDT_PA=0 switches it off) and the
+    cost-ordered tickets of the persistent launch (MDT_NO_ORDER=1 switches them off) must not change a single bit of
+    any output: same ranks, same fixed-point moments, every parameter computed independently of its ticket."""
+    import torch
+    rng = np.random.default_rng(31)
+    cases = []
+    x = ar1(0.5, 4000, 4, 24, rng)                 # n = 16 000: two-level ranking, 8 split chains of 2000
+    x[:, :, 3] = np.round(x[:, :, 3], 1)           # heavy ties
+    x[:, 1, 5] += 0.7
+    cases.append(("f64 4 chains", dev(x), None))
+    x16 = ar1(0.3, 1500, 16, 6, rng).astype(np.float32)   # 32 split chains, Float32 (config 5's shape in small)
+    cases.append(("f32 16 chains", dev(x16), np.repeat(np.arange(1, 5), 4)))
+    xo = ar1(0.2, 3001, 4, 5, rng)                 # odd draws: rows are dropped by the split -> the two-pass form serves it
+    cases.append(("odd draws", dev(xo), None))
+    big = torch.randn(2600, 2, 8000, dtype=torch.float64, device="cuda").permute(2, 1, 0)  # > 4 tickets per workgroup: ordered launches
+    cases.append(("many params", big, None))
+
+    def run_all(xd, ids):
+        out = [host(o) for o in pkg.bulk_tail(xd)]
+        out.append(host(pkg.rhat(xd)))
+        out.append(host(pkg.ess(xd, kind="tail")))
+        if ids is not None:
+            out.append(host(pkg.rhat_nested(xd, ids, kind="rank")))
+        return out
+
+    for what, xd, ids in cases:
+        monkeypatch.delenv("MDT_PA", raising=False)
+        monkeypatch.delenv("MDT_NO_ORDER", raising=False)
+        a = run_all(xd, ids)
+        a2 = run_all(xd, ids)                      # second round: the tickets follow the measured costs now
+        monkeypatch.setenv("MDT_PA", "0")
+        b = run_all(xd, ids)
+        monkeypatch.setenv("MDT_NO_ORDER", "1")
+        c = run_all(xd, ids)
+        for u, v, w, y in zip(a, a2, b, c):
+            assert np.array_equal(u, v, equal_nan=True), what + ": ticket order"
+            assert np.array_equal(u, w, equal_nan=True), what + ": tile-major partition"
+            assert np.array_equal(u, y, equal_nan=True), what + ": no order"
+    monkeypatch.delenv("MDT_PA", raising=False)
+    monkeypatch.delenv("MDT_NO_ORDER", raising=False)
+
+
 def test_fewer_draws_than_splits(pkg):
     """draws < split_chains: niter == 0, everything is NaN (mean of nothing, src/ess_rhat.jl:391-406) -- and the
     kernel's early exit from a parameter must not wedge the workgroup (it did once)"""

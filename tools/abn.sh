@@ -6,6 +6,6 @@ for r in $(seq $N); do
   for v in "$@"; do
     cp $v $L
     echo -n "$(basename $v) "
-    python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"
+    python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-other-configs 2>/dev/null | tail -1 | python -c "import json,sys; print(json.loads(sys.stdin.read())['ms_per_step'])"
   done
 done
