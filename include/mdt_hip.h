@@ -156,6 +156,17 @@ int mdt_rhat_nested(mdt_ctx* ctx, const mdt_args* args, const void* x, const int
  * std over all draws and chains divided by sqrt(ESS)).  args->kind is ignored. */
 int mdt_mcse_mean(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);
 
+/*
+ * mcse(x; kind=Statistics.mean) AND rhat_nested(x, superchain_ids; kind) from one visit to every parameter (BASELINE
+ * config 5 asks for both on the same array): replaces src/mcse.jl:45-51 and src/rhat_nested.jl:83-188 in one launch --
+ * a parameter's slice is read from HBM once, the ranking passes that follow find it in the caches.  Same results, bit
+ * for bit, as mdt_mcse_mean and mdt_rhat_nested called one after the other.  args->kind selects the nested R-hat
+ * (MDT_KIND_BASIC .. MDT_KIND_RANK); autocov / maxlag / split_chains are those of mcse (rhat_nested has none of its
+ * own besides split_chains).  chain_inds, K, S as for mdt_rhat_nested.
+ */
+int mdt_mcse_nested(mdt_ctx* ctx, const mdt_args* args, const void* x, const int32_t* chain_inds, int32_t K, int32_t S,
+                    void* mcse_out, void* rhat_out);
+
 /* mcse(x; kind=Statistics.std) -- replaces src/mcse.jl:52-65 (ESS of the proxy (x - mean)^2, then the delta
  * method sqrt((E[mu4]/E[var] - E[var]) / S) / 2).  args->kind is ignored. */
 int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* args, const void* x, void* mcse_out);

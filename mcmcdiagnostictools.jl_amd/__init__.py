@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     from_mcmcchains_layout,
     gelmandiag,
     mcse,
+    mcse_rhat_nested,
     rank_normalize,
     rhat,
     rhat_nested,

@@ -20,7 +20,7 @@ OUT_ESS, OUT_RHAT = 1, 2
 
 # every symbol include/mdt_hip.h declares
 SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_create_multi", "mdt_ctx_destroy", "mdt_ctx_status", "mdt_last_error", "mdt_ess_rhat",
-           "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile", "mdt_rank_normalize", "mdt_layout_from_dpc",
+           "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile", "mdt_rank_normalize", "mdt_layout_from_dpc",
            "mdt_bfmi", "mdt_gelmandiag", "mdt_debug_phase_cycles", "mdt_debug_beta")
 
 
@@ -85,6 +85,7 @@ def load():
         lib.mdt_ess_rhat.argtypes = [vp, ap, vp, vp, vp]
         lib.mdt_bulk_tail.argtypes = [vp, ap, vp, vp, vp, vp, vp]
         lib.mdt_rhat_nested.argtypes = [vp, ap, vp, vp, i32, i32, vp]
+        lib.mdt_mcse_nested.argtypes = [vp, ap, vp, vp, i32, i32, vp, vp]
         lib.mdt_mcse_mean.argtypes = [vp, ap, vp, vp]
         lib.mdt_mcse_std.argtypes = [vp, ap, vp, vp]
         lib.mdt_mcse_quantile.argtypes = [vp, ap, vp, vp]

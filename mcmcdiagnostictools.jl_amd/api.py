@@ -391,6 +391,31 @@ def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, devices
     return _finish(pr, out)
 
 
+def mcse_rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, maxlag=250, autocov_method=None,
+                     devices=None):
+    """(mcse(samples; kind=mean), rhat_nested(samples, superchain_ids; kind)) from ONE launch (mdt_mcse_nested): every
+    parameter's slice is read from HBM once for both (BASELINE config 5).  Bit-identical to the two separate calls."""
+    nd = samples.ndim if hasattr(samples, "ndim") else np.asarray(samples).ndim
+    if nd < 2:
+        raise ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`")
+    split_chains = _check_int("split_chains", split_chains)
+    maxlag = _check_int("maxlag", maxlag)
+    autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
+    inds = _validate_superchain_ids(superchain_ids, samples.shape[1])
+    kind = _norm_kind(kind)
+    if kind not in _KINDS:
+        raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat_nested`")
+    pr = _prepare(samples, allow_strided=devices is None)
+    _warn_niter(pr, split_chains)
+    m_out, r_out = _new_out(pr), _new_out(pr)
+    if pr.P > 0:
+        h = _ctx_key(pr, devices)
+        a = _args(pr, _lib.KIND[kind], 3, autocov, split_chains, maxlag, False, 0.1)
+        K, S = inds.shape
+        _call(h, _lib.load().mdt_mcse_nested, ctypes.byref(a), pr.ptr, inds.ctypes.data, K, S, _optr(m_out), _optr(r_out))
+    return _finish(pr, m_out), _finish(pr, r_out)
+
+
 def mcse(samples, *, kind=np.mean, **kwargs):
     """Monte Carlo standard error for kind = mean (src/mcse.jl:45-51), std (:52-65), median or Quantile(p)
     (:66-118: Beta quadrature points + two order statistics); the SBM fallback for arbitrary estimators is

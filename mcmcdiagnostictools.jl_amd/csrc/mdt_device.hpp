@@ -40,6 +40,7 @@
 // Every constant below derives from those macros; the host picks the geometry per request.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #if !defined(MDT_NS) || !defined(MDT_NT) || !defined(MDT_LDS_LIMIT) || !defined(MDT_WAVES_PER_EU)
 #error "define MDT_NS, MDT_NT, MDT_LDS_LIMIT and MDT_WAVES_PER_EU before including mdt_device.hpp"
@@ -123,7 +124,7 @@ struct KP {
     long long D, C, P, n;       // draws, chains, params, n = D*C
     long long niter;            // D / s
     int s, rem, m;              // split_chains, D % s, m = C*s
-    int mode;                   // 0 ess_rhat / bulk_tail, 1 rhat_nested, 2 mcse_mean, 3 rank_normalize stage
+    int mode;                   // 0 ess_rhat / bulk_tail, 1 rhat_nested, 2 mcse_mean, 3 rank_normalize stage, 4 mcse_std, 5 mcse quantile pass 2, 6 mcse_mean + rhat_nested
     int basic;                  // kind == basic (no ranking); outputs via out_eb / out_rb
     int need_eb, need_rb, need_et, need_rt; // bulk ESS / bulk Rhat / tail ESS / tail Rhat
     int method;                 // 0 direct, 1 fft, 2 bda
@@ -152,6 +153,7 @@ struct KP {
     long long n_pad;
     void* out_eb; void* out_rb; void* out_et; void* out_rt; // [P] of T, or null
     void* out_rrank;            // [P] max(rhat_tail, rhat_bulk) (kind = rank), or null
+    void* out_mcse;             // mode 6 (mcse(mean) + rhat_nested fused): [P] mcse
     double* rank_out;           // stage: [P*n] tied ranks
     void* z_out;                // stage: [P*n] normal scores (T)
     const int* chain_inds;      // nested: K x S (device)
@@ -627,28 +629,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             continue;
         }
 
-        if (kp.basic && kp.mode != 3) {
+        // raw draws (kind = basic, mcse(mean)): rmode = 0 ess_rhat, 1 nested R-hat, 2 mcse(mean) into out_m
+        auto raw_request = [&](int rmode, bool r_need_eb, void* out_m) {
             // raw draws: moments (and R-hat) from the streaming sweep of series_z_phase<RAW>, whatever follows --
             // rhat(x) and ess_rhat(x).rhat are the same bits; then the autocovariance: the in-LDS FFT if asked
             // for, the one-chain-per-LDS-buffer sweep when a split chain fits, the tiled series_phase otherwise
-            const bool acov = kp.need_eb && kp.ess_ok;
+            const bool acov = r_need_eb && kp.ess_ok;
             if (many) { // more split chains than the moment tables hold: one thread per split chain (many_phase)
                 const SeriesOut sm = many_phase(kp, YX, xs, acov, smem);
                 const double ess = acov ? sm.ess : nan;
-                if (kp.mode == 2) { // pooled corrected std over all draws and chains (src/mcse.jl:50), two passes
+                if (rmode == 2) { // pooled corrected std over all draws and chains (src/mcse.jl:50), two passes
                     double loc = 0.0;
                     for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
                     const double mu = wg_sum(loc, red) / (double)n;
                     loc = 0.0;
                     for (long long e = tid; e < n; e += NT) { const double d = (double)xp[e] - mu; loc = fma(d, d, loc); }
                     const double var = wg_sum(loc, red) / (double)(n - 1);
-                    if (tid == 0) store_out<T>(kp.out_eb, p, sqrt(var) / sqrt(ess));
+                    if (tid == 0) store_out<T>(out_m, p, sqrt(var) / sqrt(ess));
                 } else if (tid == 0) {
-                    if (kp.mode != 1) store_out<T>(kp.out_eb, p, ess);
+                    if (rmode != 1) store_out<T>(kp.out_eb, p, ess);
                     store_out<T>(kp.out_rb, p, sm.rhat);
                 }
                 __syncthreads();
-                continue;
+                return;
             }
             // (a split chain that fits the LDS: the autocovariance sweep takes the moments itself, from the chain it holds --
             // same virtual threads, order and expressions as the streaming sweep, so the same bits -- one pass over x less)
@@ -664,11 +667,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 so.ess = fft_lds ? sa.ess : fft_const_chain_nan(sa.ess);
             }
             double ess = acov ? so.ess : nan;
-            if (kp.mode == 1) {
+            if (rmode == 1) {
                 const double r = nested_combine_wg(kp, mean_j, var_j, smem);
                 if (tid == 0) store_out<T>(kp.out_rb, p, r);
                 __syncthreads();
-            } else if (kp.mode == 2 && kp.rem == 0) {
+            } else if (rmode == 2 && kp.rem == 0) {
                 // pooled corrected std over all draws and chains (src/mcse.jl:50).  Every draw belongs to a split chain
                 // here, so the pooled moments follow from the split-chain ones already in LDS (Chan's combination:
                 // sum of squares about the pooled mean = sum_j [(niter - 1) var_j + niter (mean_j - mu)^2]) -- no further
@@ -679,10 +682,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                     mu /= (double)kp.m;
                     double ss = 0.0;
                     for (int j = 0; j < kp.m; ++j) { const double d = mean_j[j] - mu; ss += (double)(kp.niter - 1) * var_j[j] + (double)kp.niter * d * d; }
-                    store_out<T>(kp.out_eb, p, sqrt(ss / (double)(n - 1)) / sqrt(ess));
+                    store_out<T>(out_m, p, sqrt(ss / (double)(n - 1)) / sqrt(ess));
                 }
                 __syncthreads();
-            } else if (kp.mode == 2) {
+            } else if (rmode == 2) {
                 // (rows dropped by the split, D % split_chains != 0: two passes over the pooled slice)
                 double loc = 0.0;
                 for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
@@ -690,14 +693,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                 loc = 0.0;
                 for (long long e = tid; e < n; e += NT) { const double d = (double)xp[e] - mu; loc = fma(d, d, loc); }
                 const double var = wg_sum(loc, red) / (double)(n - 1);
-                if (tid == 0) store_out<T>(kp.out_eb, p, sqrt(var) / sqrt(ess));
+                if (tid == 0) store_out<T>(out_m, p, sqrt(var) / sqrt(ess));
             } else if (tid == 0) {
                 store_out<T>(kp.out_eb, p, ess);
                 store_out<T>(kp.out_rb, p, so.rhat);
             }
             MDT_PROF_MARK(PH_SERB);
+        };
+        // fused request (mdt_mcse_nested, BASELINE config 5): mcse(kind = mean) of the raw draws (src/mcse.jl:45-51), then
+        // rhat_nested(kind) below, from the same visit to the parameter: its slice is read from HBM once, the later passes
+        // find it in the caches
+        const bool fused_mn = kp.mode == 6;
+        if (fused_mn) {
+            raw_request(2, true, kp.out_mcse);
+            __syncthreads();
+            if (kp.basic) { raw_request(1, false, nullptr); continue; } // rhat_nested(kind = basic): raw draws again
+        } else if (kp.basic && kp.mode != 3) {
+            raw_request(kp.mode, kp.need_eb != 0, kp.out_eb);
             continue;
         }
+        const bool nested = kp.mode == 1 || fused_mn;
 
 
         // ---- ranking of x; capture median / quantile neighbours on the way
@@ -739,7 +754,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
                                   // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
                                   (est_ind || kp.mode == 5 || (!(kp.need_eb || kp.need_rb) && kp.mode != 3)) ? 4
                                       // nested R-hat only needs the moments (and has no ess_rhat twin whose bits it must match)
-                                      : ((kp.mode == 1 && !kp.need_eb) ? 2 : (seg_req ? 1 : (long_chain ? ((kp.need_eb && kp.ess_ok) ? 3 : 2) : 0))),
+                                      : ((nested && !kp.need_eb) ? 2 : (seg_req ? 1 : (long_chain ? ((kp.need_eb && kp.ess_ok) ? 3 : 2) : 0))),
                                   // the folded ranking that follows is a merge of the sorted slice (fold_merge_phase)
                                   kp.need_rt && kp.mode != 3 && kp.fold_merge && !many); // (many chains: the sorted copy's scratch holds their moments)
                 if (!rk) rank_phase_p(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3);
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             }
             rb = so.rhat;
             if (acov) eb = so.ess;
-            if (kp.mode == 1 && !many) rb = nested_combine_wg(kp, mean_j, var_j, smem);
+            if (nested && !many) rb = nested_combine_wg(kp, mean_j, var_j, smem);
         }
         MDT_PROF_MARK(PH_SERB);
         if (kp.need_rt) {
@@ -910,7 +925,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             } else {
                 rt = series_z_phase<false>(kp, zb, nullptr, false, smem).rhat;
             }
-            if (kp.mode == 1 && !many) rt = nested_combine_wg(kp, mean_j, var_j, smem);
+            if (nested && !many) rt = nested_combine_wg(kp, mean_j, var_j, smem);
             MDT_PROF_MARK(PH_SERT);
         }
         if (kp.need_et && kp.ess_ok) {

@@ -438,6 +438,7 @@ struct Req {
     int need_eb = 0, need_rb = 0, need_et = 0, need_rt = 0;
     void* out_eb = nullptr; void* out_rb = nullptr; void* out_et = nullptr; void* out_rt = nullptr;
     void* out_rrank = nullptr;
+    void* out_mcse = nullptr; // mode 6
     double* rank_out = nullptr; void* z_out = nullptr;
     int fold = 0;
     int est = 0; // ess(kind = estimator): MDT_KIND_MEDIAN .. MDT_KIND_QUANTILE
@@ -514,7 +515,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // a context serves one stream at a time: work queued on another stream may still use the scratch and the status words
     if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
     // nested R-hat: split chains per superchain and superchains the combine step holds in LDS
-    if (rq.mode == 1) {
+    if (rq.mode == 1 || rq.mode == 6) {
         const long long mkmax = tiny ? mdt_tiny::NEST_MK : mdt_small::NEST_MK, smax = tiny ? mdt_tiny::NEST_S : mdt_small::NEST_S;
         static_assert(mdt_small::NEST_MK == mdt_big::NEST_MK && mdt_small::NEST_S == mdt_big::NEST_S, "one limit for the 80 / 160 KiB geometries");
         if ((long long)rq.K * s > mkmax || rq.S > smax)
@@ -523,21 +524,22 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
 
     // host staging
     const void* dx = x;
-    void* outs_host[5] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank};
-    void* outs_dev[5] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank};
+    constexpr int NOUT = 6;
+    void* outs_host[NOUT] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank, rq.out_mcse};
+    void* outs_dev[NOUT] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank, rq.out_mcse};
     double* rank_host = rq.rank_out; void* z_host = rq.z_out;
     if (a->location == MDT_HOST) {
         const size_t xb = (size_t)((P - 1) * ps + (C - 1) * cs + D) * ts; // the extent of x, whatever lies between its pieces
         if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
         HIP_TRY(hipMemcpyAsync(ctx->stage_x, x, xb, hipMemcpyHostToDevice, st));
         dx = ctx->stage_x;
-        size_t ob = 5 * (size_t)P * ts;
+        size_t ob = NOUT * (size_t)P * ts;
         if (rq.mode == 3) ob += (size_t)n * P * (8 + ts) + 16; // (+ the 16-byte alignment of the stage arrays)
         if (int rcs = stage_out_bytes(ctx, ob)) return rcs;
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < NOUT; ++i)
             outs_dev[i] = outs_host[i] ? (void*)((char*)ctx->stage_out + (size_t)i * P * ts) : nullptr;
         if (rq.mode == 3) {
-            char* base = (char*)ctx->stage_out + 5 * (size_t)P * ts;
+            char* base = (char*)ctx->stage_out + NOUT * (size_t)P * ts;
             base = (char*)(((uintptr_t)base + 15) & ~(uintptr_t)15);
             if (rank_host) rq.rank_out = (double*)base;
             if (z_host) rq.z_out = base + (size_t)n * P * 8;
@@ -562,7 +564,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         rc = ensure_ztab(ctx, n, f32 ? 1 : 0, st);
         if (rc) return rc;
     }
-    if (rq.mode == 1) {
+    if (rq.mode == 1 || rq.mode == 6) {
         const int cnt = rq.K * rq.S;
         if (cnt > ctx->chain_inds_cap) {
             if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
@@ -638,6 +640,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     { const char* pe = getenv("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
+    kp.out_mcse = outs_dev[5];
     kp.rank_out = rq.rank_out; kp.z_out = rq.z_out;
     kp.chain_inds = ctx->chain_inds; kp.K = rq.K; kp.S = rq.S;
     kp.tpos_arr = rq.tpos_arr;
@@ -691,7 +694,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     ctx->used = true;
 
     if (a->location == MDT_HOST) {
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < NOUT; ++i)
             if (outs_host[i]) HIP_TRY(hipMemcpyAsync(outs_host[i], outs_dev[i], (size_t)P * ts, hipMemcpyDeviceToHost, st));
         if (rq.mode == 3) {
             if (rank_host) HIP_TRY(hipMemcpyAsync(rank_host, rq.rank_out, (size_t)n * P * 8, hipMemcpyDeviceToHost, st));
@@ -719,7 +722,7 @@ int run_shard(mdt_ctx* child, const mdt_args* a, const void* x, const Req& rq, l
     b.params = cnt;
     b.sync = 1;
     const char* xs = (const char*)x + (size_t)lo * n * ts;
-    void* Req::*outs[5] = {&Req::out_eb, &Req::out_rb, &Req::out_et, &Req::out_rt, &Req::out_rrank};
+    void* Req::*outs[6] = {&Req::out_eb, &Req::out_rb, &Req::out_et, &Req::out_rt, &Req::out_rrank, &Req::out_mcse};
     Req r = rq;
     if (a->location == MDT_HOST || child->device == owner_dev) {
         for (auto o : outs) if (r.*o) r.*o = (char*)(r.*o) + (size_t)lo * ts;
@@ -731,7 +734,7 @@ int run_shard(mdt_ctx* child, const mdt_args* a, const void* x, const Req& rq, l
     MDT_ON_DEVICE(child);
     const size_t xb = (size_t)cnt * n * ts;
     if (int rc = stage_x_bytes(child, xb)) return rc;
-    if (int rc = stage_out_bytes(child, 5 * (size_t)cnt * ts)) return rc;
+    if (int rc = stage_out_bytes(child, 6 * (size_t)cnt * ts)) return rc;
     HIP_TRY(hipMemcpyPeer(child->stage_x, child->device, xs, owner_dev, xb));
     int k = 0;
     for (auto o : outs) { if (r.*o) r.*o = (char*)child->stage_out + (size_t)k * cnt * ts; ++k; }
@@ -750,7 +753,7 @@ int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq) {
     if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
     if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
     if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "a multi-GPU context takes the dense layout only");
-    if ((rq.mode > 2 && rq.mode != 4) || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
+    if ((rq.mode > 2 && rq.mode != 4 && rq.mode != 6) || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     const long long P = a->params;
     if (P == 0) return MDT_OK;
     if (!x) return fail(ctx, MDT_EARG, "x is NULL");
@@ -992,6 +995,30 @@ int mdt_rhat_nested(mdt_ctx* ctx, const mdt_args* a, const void* x, const int32_
     case MDT_KIND_BULK: rq.need_rb = 1; rq.out_rb = rhat_out; break;
     case MDT_KIND_TAIL: rq.need_rt = 1; rq.out_rt = rhat_out; break;
     case MDT_KIND_RANK: rq.need_rb = 1; rq.need_rt = 1; rq.out_rrank = rhat_out; break; // map(max, Rbulk, Rtail), :124
+    default: return fail(ctx, MDT_EARG, "the `kind` is not supported by `rhat_nested`"); // :64
+    }
+    return run(ctx, a, x, rq);
+}
+
+int mdt_mcse_nested(mdt_ctx* ctx, const mdt_args* a, const void* x, const int32_t* chain_inds, int32_t K, int32_t S,
+                    void* mcse_out, void* rhat_out) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (!chain_inds || !rhat_out || !mcse_out) return fail(ctx, MDT_EARG, "NULL pointer");
+    if (S < 2) return fail(ctx, MDT_EARG, "at least 2 superchains are required"); // src/rhat_nested.jl:76-77
+    if (K < 1 || (long long)K * S != a->chains)
+        return fail(ctx, MDT_EDIM, "`superchain_ids` does not cover the chains of `samples`"); // :69-73
+    for (int i = 0; i < K * S; ++i)
+        if (chain_inds[i] < 0 || chain_inds[i] >= a->chains) return fail(ctx, MDT_EARG, "chain index out of range");
+    Req rq;
+    rq.mode = 6;
+    rq.chain_inds = chain_inds; rq.K = K; rq.S = S;
+    rq.out_mcse = mcse_out; rq.want_ess = 1; // (mcse needs the basic ESS: the maxlag domain check of src/ess_rhat.jl:481 applies)
+    switch (a->kind) {
+    case MDT_KIND_BASIC: rq.basic = 1; rq.need_rb = 1; rq.out_rb = rhat_out; break;
+    case MDT_KIND_BULK: rq.need_rb = 1; rq.out_rb = rhat_out; break;
+    case MDT_KIND_TAIL: rq.need_rt = 1; rq.out_rt = rhat_out; break;
+    case MDT_KIND_RANK: rq.need_rb = 1; rq.need_rt = 1; rq.out_rrank = rhat_out; break; // map(max, Rbulk, Rtail), src/rhat_nested.jl:124
     default: return fail(ctx, MDT_EARG, "the `kind` is not supported by `rhat_nested`"); // :64
     }
     return run(ctx, a, x, rq);

@@ -522,10 +522,13 @@ def test_tile_major_partition_and_ticket_order_change_no_bit(pkg, monkeypatch):
         return out
 
     for what, xd, ids in cases:
-        monkeypatch.delenv("MDT_PA", raising=False)
+        monkeypatch.setenv("MDT_PA", "2")           # the tile-major partition wherever it can run (the default takes it for long chains only)
         monkeypatch.delenv("MDT_NO_ORDER", raising=False)
         a = run_all(xd, ids)
         a2 = run_all(xd, ids)                      # second round: the tickets follow the measured costs now
+        monkeypatch.delenv("MDT_PA", raising=False)
+        for u, v in zip(a, run_all(xd, ids)):
+            assert np.array_equal(u, v, equal_nan=True), what + ": default choice"
         monkeypatch.setenv("MDT_PA", "0")
         b = run_all(xd, ids)
         monkeypatch.setenv("MDT_NO_ORDER", "1")
@@ -536,6 +539,40 @@ def test_tile_major_partition_and_ticket_order_change_no_bit(pkg, monkeypatch):
             assert np.array_equal(u, y, equal_nan=True), what + ": no order"
     monkeypatch.delenv("MDT_PA", raising=False)
     monkeypatch.delenv("MDT_NO_ORDER", raising=False)
+
+
+def test_fused_mcse_and_nested_rhat(pkg):
+    """mdt_mcse_nested (BASELINE config 5 in one launch): bit-identical to mcse(mean) and rhat_nested called one after
+    the other, within 1e-6 of the oracle (Float32: of its Float64-internal comparator), for every nested kind, on the
+    config-5 per-parameter shape (10 000 draws x 16 chains, four superchains) and on small / odd / many-chain shapes"""
+    from oracle import c_oracle
+    rng = np.random.default_rng(41)
+    ids = np.repeat(np.arange(1, 5), 4)
+    inds = np.arange(16, dtype=np.int32).reshape(4, 4, order="F")
+    shapes = [((10000, 16, 5), np.float32), ((10000, 16, 3), np.float64), ((301, 16, 4), np.float32), ((40, 16, 6), np.float64)]
+    for shape, dt in shapes:
+        x = (ar1(0.6, *shape, rng) + 0.2 * rng.standard_normal((1, 16, shape[2]))).astype(dt)
+        xd = dev(x)
+        for kind in KINDS:
+            m, r = pkg.mcse_rhat_nested(xd, ids, kind=kind)
+            m2, r2 = pkg.mcse(xd), pkg.rhat_nested(xd, ids, kind=kind)
+            assert np.array_equal(host(m), host(m2), equal_nan=True), (shape, kind, "mcse bits")
+            assert np.array_equal(host(r), host(r2), equal_nan=True), (shape, kind, "nested bits")
+            assert_close(host(m), c_oracle.mcse_mean(x), 1e-6, f"{shape} mcse")
+            assert_close(host(r), c_oracle.rhat_nested(x, inds, kind=kind), 1e-6, f"{shape} nested {kind}")
+    # host memory, and the errors of the two functions it fuses
+    x = ar1(0.3, 200, 16, 3, rng)
+    m, r = pkg.mcse_rhat_nested(x, ids)
+    assert_close(m, c_oracle.mcse_mean(x), RTOL64, "host mcse")
+    assert_close(r, c_oracle.rhat_nested(x, inds, kind="rank"), RTOL64, "host nested")
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.mcse_rhat_nested(x, ids[:5])
+    with pytest.raises(pkg.ArgumentError):
+        pkg.mcse_rhat_nested(x, np.ones(16, dtype=int))
+    with pytest.raises(pkg.DomainError):
+        pkg.mcse_rhat_nested(x, ids, maxlag=0)
+    m1, r1 = pkg.mcse_rhat_nested(dev(x), ids, devices=[0])          # the multi-GPU context takes it too
+    assert np.array_equal(host(m1), m) and np.array_equal(host(r1), r)
 
 
 def test_fewer_draws_than_splits(pkg):
