@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MDT_VERSION 200 /* 0.2.0: mdt_args gained chain_stride / param_stride; mdt_ctx_status; mdt_ctx_create_multi */
+#define MDT_VERSION 300 /* 0.3.0: mdt_args gained x_shards (pre-sharded input of a multi-GPU context); mdt_shard_bounds; mdt_mcse_nested */
 
 /* status codes (the Julia shim maps them to the reference's exception types) */
 #define MDT_OK 0
@@ -92,6 +92,13 @@ typedef struct mdt_args {
     void* stream;                  /* hipStream_t to enqueue on, or NULL for the default stream */
     int64_t chain_stride;          /* elements between the first draws of consecutive chains; 0: draws */
     int64_t param_stride;          /* elements between consecutive parameters; 0: draws*chains */
+    const void* const* x_shards;   /* multi-GPU context only, or NULL: the input PRE-SHARDED -- x_shards[i] is block i of the params axis
+                                      (mdt_shard_bounds(params, i, ndev)), resident on device_ids[i] (MDT_DEVICE) or in host memory
+                                      (MDT_HOST), same draws / chains / strides as `args` says; the `x` argument is then ignored */
+    double tail_p_lo, tail_p_hi;   /* both nonzero: the two quantile probabilities of ess(kind = :tail) themselves -- pl, pu of
+                                      src/ess_rhat.jl:305-307 as the caller evaluated them in ITS arithmetic (Julia: convert(T,
+                                      tail_prob / 2), convert(T, 1 - tail_prob / 2) with a Rational tail_prob); 0, 0: derived here as
+                                      tail_prob / 2 and 1 - tail_prob / 2 in double (one ulp from the Rational result at most) */
 } mdt_args;
 
 int mdt_version(void);
@@ -104,14 +111,25 @@ const char* mdt_last_error(const mdt_ctx* ctx);
 /*
  * One context over several GPUs of the node: every parameter is independent (the `for` over
  * _eachparam, src/ess_rhat.jl:517), so mdt_ess_rhat (every kind and estimator) / mdt_bulk_tail / mdt_rhat_nested /
- * mdt_mcse_mean / mdt_mcse_std on such a context cut the params axis into ndev contiguous blocks (block i = params [i*P/ndev, (i+1)*P/ndev)), run block
- * i on device_ids[i] concurrently (one host thread and one stream per device, no exchange during compute) and
- * leave every output vector complete in the caller's buffer.  location == MDT_HOST: each block is staged to its
- * own GPU over PCIe.  location == MDT_DEVICE: x and the outputs live on ONE of the devices (found from the
- * pointer); the other devices fetch their block and return their results by peer copies over xGMI.
- * Calls on a multi-GPU context are synchronous on return.  Dense layout only (strides 0).  ndev == 1 is allowed.
+ * mdt_mcse_nested / mdt_mcse_mean / mdt_mcse_std / mdt_mcse_quantile on such a context cut the params axis into ndev
+ * contiguous blocks -- block i = mdt_shard_bounds(params, i, ndev): the first params mod ndev blocks hold one parameter
+ * more --, run block i on device_ids[i] concurrently (one persistent worker thread and one stream per device, no exchange
+ * during compute) and leave every output vector complete in the caller's buffer.
+ *   Input, three forms: (a) PRE-SHARDED, args->x_shards[i] = block i already resident on device_ids[i] -- no input moves
+ *   at all; the only form for arrays that exceed one GPU (BASELINE config 4 is 320 GB); (b) location == MDT_HOST: each
+ *   block is staged to its own GPU over PCIe (x or x_shards); (c) location == MDT_DEVICE with a single x: the array
+ *   lives on ONE GPU (found from the pointer), the others fetch their block by a peer copy over xGMI -- a convenience
+ *   for arrays that are already there, not a fast path.
+ *   Outputs: [params] vectors in host memory, or on one of the devices (found from the pointer); every block's results
+ *   reach them by one copy per output (in place when the block's GPU owns them).
+ * Strided layouts (chain_stride / param_stride) are honoured per block.  Calls on a multi-GPU context are synchronous
+ * on return.  ndev == 1 is allowed.
  */
 int mdt_ctx_create_multi(mdt_ctx** out, const int* device_ids, int ndev);
+
+/* The partition rule of a multi-GPU context (and of the one-process-per-GPU mirror, dist.shard_bounds): block `shard`
+ * of `nshards` is params [lo, hi).  Pure arithmetic, no GPU is touched. */
+int mdt_shard_bounds(int64_t params, int32_t shard, int32_t nshards, int64_t* lo, int64_t* hi);
 
 /* flags of mdt_ctx_status */
 #define MDT_FLAG_RANK_OVERFLOW 1 /* draws*chains exceeded the ranking tables: the outputs of that parameter are NaN */

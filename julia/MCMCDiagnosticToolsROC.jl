@@ -12,12 +12,16 @@
 #     (src/ess_rhat.jl:464-467, src/utils.jl:197-215; test/ess_rhat.jl:134-165 with OffsetArrays);
 #   * `Int` input is promoted to Float64 (src/ess_rhat.jl:353, 465);
 #   * device arrays (AMDGPU.jl `ROCArray`) are passed by pointer with `location = MDT_DEVICE`: no host copy;
-#   * `devices = [0, 1, ...]`: the multi-GPU context (mdt_ctx_create_multi), params axis cut into contiguous blocks.
+#   * `devices = [0, 1, ...]`: the multi-GPU context (mdt_ctx_create_multi), params axis cut into contiguous blocks
+#     (block i = `shard_bounds(P, i, n)`, one rule everywhere); a `Vector` of ROCArrays, block i on GPU devices[i], is
+#     taken PRE-SHARDED (mdt_args.x_shards): no input moves between GPUs;
+#   * a `PermutedDimsArray` view of (iterations, parameters, chains) storage -- what MCMCChains keeps -- is read in
+#     place through chain_stride / param_stride (`samples_from_chains`), no `permutedims` copy.
 module MCMCDiagnosticToolsROC
 
 using Statistics: Statistics
 
-export ess, rhat, ess_rhat, rhat_nested, mcse, bfmi, gelmandiag, status, UnsupportedOnDevice
+export ess, rhat, ess_rhat, rhat_nested, mcse, mcse_rhat_nested, bfmi, gelmandiag, status, shard_bounds, samples_from_chains, UnsupportedOnDevice
 export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
 
 const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")
@@ -50,9 +54,15 @@ struct MdtArgs
     stream::Ptr{Cvoid}
     chain_stride::Int64   # 0: dense
     param_stride::Int64   # 0: dense
+    x_shards::Ptr{Ptr{Cvoid}}   # multi-GPU context: block i of the params axis on device i (pre-sharded), or C_NULL
+    tail_p_lo::Float64          # pl, pu of src/ess_rhat.jl:306-307 evaluated HERE, in the caller's arithmetic (0, 0: derived in the library)
+    tail_p_hi::Float64
 end
 MdtArgs(D, C, P, dtype, location, kind, outputs, autocov, split, relative, sync, maxlag, tail_prob, stream) =
-    MdtArgs(D, C, P, dtype, location, kind, outputs, autocov, split, relative, sync, maxlag, tail_prob, stream, 0, 0)
+    MdtArgs(D, C, P, dtype, location, kind, outputs, autocov, split, relative, sync, maxlag, tail_prob, stream, 0, 0, C_NULL, 0.0, 0.0)
+_with_layout(a::MdtArgs, cs, ps, shards=C_NULL, pl=a.tail_p_lo, pu=a.tail_p_hi) =
+    MdtArgs(a.draws, a.chains, a.params, a.dtype, a.location, a.kind, a.outputs, a.autocov, a.split_chains, a.relative,
+            a.sync, a.maxlag, a.tail_prob, a.stream, cs, ps, shards, pl, pu)
 
 const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
 const _multi = Dict{Vector{Cint},Ptr{Cvoid}}()
@@ -81,8 +91,21 @@ Sticky condition flags of the context (mdt_ctx_status): 1 ranking tables overflo
 NaN (the reference throws ArgumentError there), 4 FDist.  Only requests issued with `sync = 0` leave flags behind."""
 function status(; devices=nothing, clear::Bool=true)
     f = Ref{Int32}(0)
-    _check(ccall((:mdt_ctx_status, libmdt), Cint, (Ptr{Cvoid}, Ref{Int32}, Int32), _ctx_for(devices), f, clear))
+    h = _ctx_for(devices)
+    _check(h, ccall((:mdt_ctx_status, libmdt), Cint, (Ptr{Cvoid}, Ref{Int32}, Int32), h, f, clear))
     return f[]
+end
+
+"""    shard_bounds(P, i, n) -> (lo, hi)
+
+Block `i` (0-based) of `n` of a params axis of length `P`, as the half-open 0-based range the library cuts by
+(mdt_shard_bounds): the first `P mod n` blocks hold one parameter more.  A caller that keeps its array pre-sharded
+over the GPUs of a node must cut by the same rule."""
+function shard_bounds(P::Integer, i::Integer, n::Integer)
+    lo, hi = Ref{Int64}(0), Ref{Int64}(0)
+    rc = ccall((:mdt_shard_bounds, libmdt), Cint, (Int64, Int32, Int32, Ref{Int64}, Ref{Int64}), P, i, n, lo, hi)
+    rc == 0 || throw(ArgumentError("shard_bounds($P, $i, $n)"))
+    return lo[], hi[]
 end
 
 """    UnsupportedOnDevice(msg)
@@ -95,9 +118,10 @@ struct UnsupportedOnDevice <: Exception
 end
 Base.showerror(io::IO, e::UnsupportedOnDevice) = print(io, "unsupported on the device path: ", e.msg)
 
-function _check(rc::Cint)
+# status -> exception; the message is read from the context the call was made on (single- or multi-GPU)
+function _check(h::Ptr{Cvoid}, rc::Cint)
     rc == 0 && return nothing
-    msg = unsafe_string(ccall((:mdt_last_error, libmdt), Cstring, (Ptr{Cvoid},), ctx()))
+    msg = unsafe_string(ccall((:mdt_last_error, libmdt), Cstring, (Ptr{Cvoid},), h))
     rc == 1 && throw(ArgumentError(msg))
     rc == 2 && throw(DomainError(0, msg))
     rc == 3 && throw(DimensionMismatch(msg))
@@ -115,12 +139,32 @@ _param_axes(x::AbstractArray) = ntuple(i -> axes(x, i + 2), max(ndims(x) - 2, 0)
 _valtype(x) = (T = float(nonmissingtype(eltype(x))); T in (Float32, Float64) ? T : Float64)
 
 struct Prepared{T,A}
-    x3::A                       # (draws, chains, params), dense, eltype T: Array or ROCArray
+    x3::A                       # the memory handed to the library: (draws, chains, params) dense, or the parent of a strided view
+    dims::NTuple{3,Int}         # logical (draws, chains, params)
+    cs::Int64                   # chain_stride / param_stride in elements (0, 0: dense)
+    ps::Int64
     missing_param::Union{Nothing,BitVector}
     location::Int32             # 0 host, 1 device
+    shards::Union{Nothing,Vector{Ptr{Cvoid}}}   # pre-sharded input of a multi-GPU context
 end
+Prepared{T,A}(x3::A, miss, loc) where {T,A} = Prepared{T,A}(x3, size(x3), 0, 0, miss, loc, nothing)
+Base.size(pr::Prepared) = pr.dims
+
+"""    samples_from_chains(value) -> view
+
+`value` is (iterations, parameters, chains) -- the storage order of `MCMCChains.Chains` (`chn.value.data`).  The
+result is the (draws, chains, parameters) view every function here takes, WITHOUT a `permutedims` copy: the library
+reads the parent in place through `chain_stride = iterations * parameters`, `param_stride = iterations`."""
+samples_from_chains(value::AbstractArray{<:Any,3}) = PermutedDimsArray(value, (1, 3, 2))
+
 function _prepare(x::AbstractArray)
     T = _valtype(x)
+    # (iterations, parameters, chains) storage viewed as (draws, chains, params): read in place through the strides
+    if x isa PermutedDimsArray{T,3,(1, 3, 2)} && (parent(x) isa Array{T,3} || _is_device(parent(x)))
+        par = parent(x)
+        D, Pn, C = size(par)
+        return Prepared{T,typeof(par)}(par, (D, C, Pn), Int64(D) * Pn, Int64(D), nothing, Int32(_is_device(par) ? 1 : 0), nothing)
+    end
     if _is_device(x)
         eltype(x) === T || throw(ArgumentError("device arrays must be Float32 or Float64"))
         return Prepared{T,typeof(x)}(reshape(x, size(x, 1), size(x, 2), :), nothing, Int32(1))
@@ -134,13 +178,36 @@ function _prepare(x::AbstractArray)
     end
     return Prepared{T,Array{T,3}}(convert(Array{T,3}, x3), miss, Int32(0))
 end
-_newout(pr::Prepared{T}, n) where {T} = pr.location == 1 ? similar(pr.x3, T, n) : Vector{T}(undef, n)
+# pre-sharded input: blocks[i] is block i of the params axis, a ROCArray on GPU devices[i] (mdt_args.x_shards)
+function _prepare(blocks::AbstractVector{<:AbstractArray})
+    isempty(blocks) && throw(ArgumentError("no blocks"))
+    all(_is_device, blocks) || throw(ArgumentError("pre-sharded input must be device arrays, block i on GPU devices[i]"))
+    T = _valtype(first(blocks))
+    b3 = [reshape(b, size(b, 1), size(b, 2), :) for b in blocks]
+    D, C = size(first(b3), 1), size(first(b3), 2)
+    all(b -> eltype(b) === T && size(b, 1) == D && size(b, 2) == C, b3) ||
+        throw(DimensionMismatch("every block must be (draws, chains, params_i) with the same draws, chains and eltype"))
+    P = sum(b -> size(b, 3), b3)
+    for (i, b) in enumerate(b3)
+        lo, hi = shard_bounds(P, i - 1, length(b3))
+        size(b, 3) == hi - lo || throw(DimensionMismatch("block $i holds $(size(b, 3)) parameters; shard_bounds gives it $(hi - lo) of $P"))
+    end
+    return Prepared{T,typeof(b3)}(b3, (D, C, P), 0, 0, nothing, Int32(1), [_ptr(b) for b in b3])
+end
+_newout(pr::Prepared{T}, n) where {T} = pr.location == 1 ? similar(pr.shards === nothing ? pr.x3 : first(pr.x3), T, n) : Vector{T}(undef, n)
+_xptr(pr::Prepared) = pr.shards === nothing ? _ptr(pr.x3) : C_NULL
+# the args of a request on `pr`: layout and (pre-sharded) block pointers filled in; `sh` must stay GC-preserved during the call
+_args_for(pr::Prepared, a::MdtArgs, sh) = _with_layout(a, pr.cs, pr.ps, sh === nothing ? Ptr{Ptr{Cvoid}}(C_NULL) : pointer(sh))
 _ptr(a) = a === nothing ? C_NULL : reinterpret(Ptr{Cvoid}, pointer(a))
 _maybescalar(x::AbstractArray{<:Any,0}) = x[]
 _maybescalar(x::AbstractArray) = x
 # similar(x, T, axes(x)[3:end]) filled with v, `missing` where a draw was missing (src/ess_rhat.jl:464-467, 519-523)
+_param_axes(x::AbstractVector{<:AbstractArray}) = (Base.OneTo(sum(b -> size(reshape(b, size(b, 1), size(b, 2), :), 3), x)),)
 function _out(x, pr::Prepared{T}, v) where {T}
-    pr.location == 1 && return _maybescalar(reshape(v, map(length, _param_axes(x))...))
+    if pr.location == 1   # device results stay on the device; a 0-dimensional result comes to the host as a scalar (no scalar indexing on the GPU)
+        pa = _param_axes(x)
+        return isempty(pa) ? Array(v)[1] : reshape(v, map(length, pa)...)
+    end
     TV = pr.missing_param === nothing ? T : Union{Missing,T}
     out = similar(x, TV, _param_axes(x))
     for (i, p) in zip(eachindex(out), eachindex(v))
@@ -156,25 +223,32 @@ function _ess_rhat(x, kind::Symbol, outputs; kindcode::Int=_KIND[kind], relative
                    maxlag::Int=250, tail_prob::Real=1//10, devices=nothing)
     _all_missing(x) && return _missing_out(x), _missing_out(x)
     pr = _prepare(x)
-    T = eltype(pr.x3)
-    D, C, P = size(pr.x3)
+    T = _valtype(x isa AbstractVector{<:AbstractArray} ? first(x) : x)
+    D, C, P = size(pr)
     niter = D ÷ split_chains
     (outputs & 1) != 0 && !(niter > 4) &&
         @warn "number of draws after splitting must be >4 but is $niter. ESS cannot be computed."
     S = (outputs & 1) != 0 ? _newout(pr, P) : nothing
     R = (outputs & 2) != 0 ? _newout(pr, P) : nothing
-    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, kindcode, outputs, _code(autocov_method),
-                split_chains, relative, 1, maxlag, Float64(tail_prob), C_NULL)
-    x3 = pr.x3
-    GC.@preserve x3 S R begin
-        _check(ccall((:mdt_ess_rhat, libmdt), Cint,
-                     (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                     _ctx_for(devices), a, _ptr(x3), _ptr(S), _ptr(R)))
+    # src/ess_rhat.jl:305-307, evaluated here exactly as the reference does (a Rational tail_prob halves exactly):
+    #   T = float(promote_type(eltype(x), typeof(tail_prob))); pl = convert(T, tail_prob / 2); pu = convert(T, 1 - tail_prob / 2)
+    # and handed over as they are (tail_p_lo / tail_p_hi): the library does not redo the arithmetic in double
+    TP = float(promote_type(T, typeof(tail_prob)))
+    pl, pu = Float64(convert(TP, tail_prob / 2)), Float64(convert(TP, 1 - tail_prob / 2))
+    tp = kindcode == _EST[:quantile] ? Float64(T(tail_prob)) : Float64(tail_prob)
+    a0 = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, kindcode, outputs, _code(autocov_method),
+                               split_chains, relative, 1, maxlag, tp, C_NULL), pr.shards)
+    a = kindcode == _EST[:quantile] ? a0 : _with_layout(a0, a0.chain_stride, a0.param_stride, a0.x_shards, pl, pu)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    GC.@preserve x3 sh S R begin
+        _check(h, ccall((:mdt_ess_rhat, libmdt), Cint,
+                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                        h, a, _xptr(pr), _ptr(S), _ptr(R)))
     end
     return S === nothing ? nothing : _out(x, pr, S), R === nothing ? nothing : _out(x, pr, R)
 end
 
-function ess(x::AbstractArray{<:Union{Missing,Real}}; kind=:bulk, kwargs...)
+function ess(x::AbstractArray; kind=:bulk, kwargs...)
     kind === Statistics.mean && return first(_ess_rhat(x, :basic, 1; kwargs...))  # src/ess_rhat.jl:629
     # the other estimators with a proxy (src/ess_rhat.jl:630-659); the probability of a quantile travels in tail_prob
     kind === Statistics.median && return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:median], kwargs...))
@@ -187,63 +261,92 @@ function ess(x::AbstractArray{<:Union{Missing,Real}}; kind=:bulk, kwargs...)
         throw(ArgumentError("the `kind` `$kind` is not supported by `ess`"))
     return first(_ess_rhat(x, kind, 1; kwargs...))
 end
-function rhat(x::AbstractArray{<:Union{Missing,Real}}; kind::Symbol=:rank, split_chains::Int=2, devices=nothing)
+function rhat(x::AbstractArray; kind::Symbol=:rank, split_chains::Int=2, devices=nothing)
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat`"))
     return last(_ess_rhat(x, kind, 2; split_chains, devices))
 end
-function ess_rhat(x::AbstractArray{<:Union{Missing,Real}}; kind::Symbol=:rank, kwargs...)
+function ess_rhat(x::AbstractArray; kind::Symbol=:rank, kwargs...)
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `ess_rhat`"))
     S, R = _ess_rhat(x, kind, 3; kwargs...)
     return (; ess=S, rhat=R)
 end
 
-function rhat_nested(x::AbstractArray{<:Union{Missing,Real}}, superchain_ids::AbstractVector; kind::Symbol=:rank,
-                     split_chains::Int=2, devices=nothing)
-    ndims(x) >= 2 || throw(ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`"))
-    length(superchain_ids) == size(x, 2) || throw(DimensionMismatch("`superchain_ids` has length $(length(superchain_ids)) but `samples` has $(size(x, 2)) chains"))
+# _validate_superchain_ids (src/rhat_nested.jl:68-81) -> K x S, 0-based, column-major
+function _superchain_inds(superchain_ids::AbstractVector, nchains::Integer)
+    length(superchain_ids) == nchains || throw(DimensionMismatch("`superchain_ids` has length $(length(superchain_ids)) but `samples` has $nchains chains"))
     ids = sort(unique(superchain_ids))
     length(ids) >= 2 || throw(ArgumentError("at least 2 superchains are required, got $(length(ids))"))
     groups = [findall(==(i), superchain_ids) for i in ids]
     allequal(length, groups) || throw(ArgumentError("all superchains must contain the same number of chains"))
-    inds = Int32.(reduce(hcat, groups) .- 1)             # K x S, 0-based, column-major
+    return Int32.(reduce(hcat, groups) .- 1)
+end
+_nchains(x::AbstractArray) = size(x, 2)
+_nchains(x::AbstractVector{<:AbstractArray}) = size(first(x), 2)
+
+function rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind::Symbol=:rank,
+                     split_chains::Int=2, devices=nothing)
+    (x isa AbstractVector{<:AbstractArray} || ndims(x) >= 2) || throw(ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`"))
+    inds = _superchain_inds(superchain_ids, _nchains(x))
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat_nested`"))
     _all_missing(x) && return _missing_out(x)
     pr = _prepare(x)
-    T = eltype(pr.x3)
-    D, C, P = size(pr.x3)
+    T = _valtype(x isa AbstractVector{<:AbstractArray} ? first(x) : x)
+    D, C, P = size(pr)
     R = _newout(pr, P)
-    a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, _KIND[kind], 2, 0, split_chains, 0, 1, 250, 0.1, C_NULL)
-    x3 = pr.x3
-    GC.@preserve x3 R inds begin
-        _check(ccall((:mdt_rhat_nested, libmdt), Cint,
-                     (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}),
-                     _ctx_for(devices), a, _ptr(x3), inds, size(inds, 1), size(inds, 2), _ptr(R)))
+    a = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, _KIND[kind], 2, 0, split_chains, 0, 1, 250, 0.1, C_NULL), pr.shards)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    GC.@preserve x3 sh R inds begin
+        _check(h, ccall((:mdt_rhat_nested, libmdt), Cint,
+                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}),
+                        h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(R)))
     end
     return _out(x, pr, R)
 end
 
-function mcse(x::AbstractArray{<:Union{Missing,Real}}; kind=Statistics.mean, autocov_method=AutocovMethod(),
+"""    mcse_rhat_nested(x, superchain_ids; kind=:rank, ...) -> (mcse, rhat_nested)
+
+`mcse(x)` (kind = mean) and `rhat_nested(x, superchain_ids; kind)` from ONE launch (mdt_mcse_nested): a parameter's
+slice is read from HBM once for both.  Bit-identical to the two calls; no counterpart in the reference."""
+function mcse_rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind::Symbol=:rank, split_chains::Int=2,
+                          maxlag::Int=250, autocov_method::AbstractAutocovMethod=AutocovMethod(), devices=nothing)
+    inds = _superchain_inds(superchain_ids, _nchains(x))
+    haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat_nested`"))
+    pr = _prepare(x)
+    T = _valtype(x isa AbstractVector{<:AbstractArray} ? first(x) : x)
+    D, C, P = size(pr)
+    M, R = _newout(pr, P), _newout(pr, P)
+    a = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, _KIND[kind], 3, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL), pr.shards)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    GC.@preserve x3 sh M R inds begin
+        _check(h, ccall((:mdt_mcse_nested, libmdt), Cint,
+                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                        h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(M), _ptr(R)))
+    end
+    return _out(x, pr, M), _out(x, pr, R)
+end
+
+function mcse(x::AbstractArray; kind=Statistics.mean, autocov_method=AutocovMethod(),
               split_chains::Int=2, maxlag::Int=250, devices=nothing)
     isq = kind === Statistics.median || kind isa Base.Fix2{typeof(Statistics.quantile),<:Real}
     kind === Statistics.mean || kind === Statistics.std || isq ||
         throw(ArgumentError("kind must be mean, std, median or Fix2(quantile, p) on the device path"))  # src/mcse.jl:45-118
     _all_missing(x) && return _missing_out(x)
     pr = _prepare(x)
-    T = eltype(pr.x3)
-    D, C, P = size(pr.x3)
+    T = _valtype(x isa AbstractVector{<:AbstractArray} ? first(x) : x)
+    D, C, P = size(pr)
     out = _newout(pr, P)
     dt = T === Float32 ? 1 : 0
-    a = MdtArgs(D, C, P, dt, pr.location, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL)
-    x3 = pr.x3
-    GC.@preserve x3 out begin
+    a = _args_for(pr, MdtArgs(D, C, P, dt, pr.location, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL), pr.shards)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)   # every kind runs on a multi-GPU context (each block on its own GPU)
+    GC.@preserve x3 sh out begin
         if isq  # kind code and probability travel in the args (src/mcse.jl:66-92)
-            aq = MdtArgs(D, C, P, dt, pr.location, kind === Statistics.median ? _EST[:median] : _EST[:quantile], 1,
-                         _code(autocov_method), split_chains, 0, 1, maxlag, kind === Statistics.median ? 0.5 : Float64(kind.x), C_NULL)
-            _check(ccall((:mdt_mcse_quantile, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), aq, _ptr(x3), _ptr(out)))
+            aq = _args_for(pr, MdtArgs(D, C, P, dt, pr.location, kind === Statistics.median ? _EST[:median] : _EST[:quantile], 1,
+                                       _code(autocov_method), split_chains, 0, 1, maxlag, kind === Statistics.median ? 0.5 : Float64(T(kind.x)), C_NULL), pr.shards)
+            _check(h, ccall((:mdt_mcse_quantile, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, aq, _xptr(pr), _ptr(out)))
         elseif kind === Statistics.mean
-            _check(ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), _ctx_for(devices), a, _ptr(x3), _ptr(out)))
+            _check(h, ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)))
         else
-            _check(ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, _ptr(x3), _ptr(out)))
+            _check(h, ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)))
         end
     end
     return _out(x, pr, out)
@@ -260,22 +363,24 @@ function bfmi(energy::AbstractMatrix{<:Real}; dims::Int=1)
     D, C = size(e2)
     out = Vector{T}(undef, C)
     a = MdtArgs(D, C, 1, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
-    GC.@preserve e2 out _check(ccall((:mdt_bfmi, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), ctx(), a, e2, out))
+    h = ctx()
+    GC.@preserve e2 out _check(h, ccall((:mdt_bfmi, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, e2, out))
     return out
 end
 
 # gelmandiag(samples; alpha) (src/gelmandiag.jl:76-80); Float64 results whatever the eltype (:41-42)
 function gelmandiag(chains::AbstractArray{<:Real,3}; alpha::Real=0.05)
     size(chains, 2) > 1 || error("Gelman diagnostic requires at least 2 chains")  # :3
-    pr = _prepare(chains)
+    pr = _prepare(chains isa PermutedDimsArray ? collect(chains) : chains)   # (the column pass reads dense arrays only)
     x3 = pr.x3
     T = eltype(x3)
     pr.location == 0 || throw(ArgumentError("gelmandiag takes host arrays in this shim"))
     D, C, P = size(x3)
     psrf, psrfci = Vector{Float64}(undef, P), Vector{Float64}(undef, P)
     a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
-    GC.@preserve x3 psrf psrfci _check(ccall((:mdt_gelmandiag, libmdt), Cint,
-        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}), ctx(), a, x3, Float64(alpha), psrf, psrfci))
+    h = ctx()
+    GC.@preserve x3 psrf psrfci _check(h, ccall((:mdt_gelmandiag, libmdt), Cint,
+        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}), h, a, x3, Float64(alpha), psrf, psrfci))
     return (psrf=psrf, psrfci=psrfci)
 end
 

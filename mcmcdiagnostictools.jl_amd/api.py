@@ -96,6 +96,11 @@ def _estimator(kind):
     return None
 
 
+def _is_shard_list(samples):
+    """a list of torch tensors: the pre-sharded input of a multi-GPU context (block i of the params axis on GPU i)"""
+    return isinstance(samples, (list, tuple)) and len(samples) > 0 and torch is not None and all(isinstance(t, torch.Tensor) for t in samples)
+
+
 class _Prepared:
     """samples flattened to (draws, chains, params) with draws-fastest memory"""
     pass
@@ -104,8 +109,11 @@ class _Prepared:
 def _prepare(samples, allow_strided=False):
     """allow_strided: a CUDA tensor whose draws are contiguous but whose chains / parameters are strided is handed
     over in place (chain_stride / param_stride of mdt_args) instead of being copied dense.  Only the entry points that
-    go through the library's run() read those strides; everything else (bfmi, gelmandiag, the stage output, a
-    multi-GPU context) gets the dense copy."""
+    go through the library's run() read those strides (a multi-GPU context included); everything else (bfmi,
+    gelmandiag, the stage output) gets the dense copy.  A list of CUDA tensors is the pre-sharded input of a multi-GPU
+    context (_prepare_shards)."""
+    if _is_shard_list(samples):
+        return _prepare_shards(samples)
     pr = _Prepared()
     mask = None
     if isinstance(samples, np.ma.MaskedArray):  # the reference's Union{Missing,T} eltype
@@ -166,6 +174,30 @@ def _prepare(samples, allow_strided=False):
     return pr
 
 
+def _prepare_shards(shards):
+    """PRE-SHARDED input of a multi-GPU context (mdt_args.x_shards): a list of CUDA tensors, block i of the params axis on
+    GPU devices[i], each of shape (draws, chains, p_i) with p_i = shard_bounds(sum p_i, i, len(shards)) -- no input
+    moves between GPUs; the outputs are gathered on the first block's GPU."""
+    prs = [_prepare(t, allow_strided=False) for t in shards]
+    p0 = prs[0]
+    if any(not q.dev for q in prs):
+        raise ArgumentError("pre-sharded input must be CUDA tensors, block i on GPU devices[i]")
+    if any((q.D, q.C, q.f32) != (p0.D, p0.C, p0.f32) for q in prs) or any(len(q.orig_shape) != 3 for q in prs):
+        raise DimensionMismatch("every block of a pre-sharded array must be (draws, chains, params_i) with the same draws, chains and eltype")
+    from .dist import shard_bounds
+    P = sum(q.P for q in prs)
+    for i, q in enumerate(prs):
+        lo, hi = shard_bounds(P, i, len(prs))
+        if q.P != hi - lo:
+            raise DimensionMismatch(f"block {i} holds {q.P} parameters; the partition rule (shard_bounds) gives it {hi - lo} of {P}")
+    pr = _Prepared()
+    pr.__dict__.update(p0.__dict__)
+    pr.P, pr.param_shape, pr.orig_shape, pr.scalar = P, (P,), (p0.D, p0.C, P), False
+    pr.ptr, pr.shards, pr.missing = None, prs, None
+    pr.xsh = (ctypes.c_void_p * len(prs))(*[q.ptr for q in prs])   # (kept alive with pr for the duration of the call)
+    return pr
+
+
 def _new_out(pr, n=None, dtype=None):
     n = pr.P if n is None else n
     if pr.torch:
@@ -185,15 +217,23 @@ def _args(pr, kind, outputs, autocov, split_chains, maxlag, relative, tail_prob,
     stream = None
     if pr.dev:
         stream = torch.cuda.current_stream(pr.buf.device).cuda_stream
-    return _lib.MdtArgs(pr.D, pr.C, pr.P, _lib.MDT_F32 if pr.f32 else _lib.MDT_F64,
-                        _lib.MDT_DEVICE if pr.dev else _lib.MDT_HOST, kind, outputs, autocov, int(split_chains),
-                        1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream,
-                        getattr(pr, "cs", 0), getattr(pr, "ps", 0))
+    a = _lib.MdtArgs(pr.D, pr.C, pr.P, _lib.MDT_F32 if pr.f32 else _lib.MDT_F64,
+                     _lib.MDT_DEVICE if pr.dev else _lib.MDT_HOST, kind, outputs, autocov, int(split_chains),
+                     1 if relative else 0, 1 if sync else 0, int(maxlag), float(tail_prob), stream,
+                     getattr(pr, "cs", 0), getattr(pr, "ps", 0))
+    if getattr(pr, "shards", None) is not None:
+        a.x_shards = ctypes.cast(pr.xsh, ctypes.POINTER(ctypes.c_void_p))
+    return a
 
 
 def _ctx_key(pr, devices=None):
     """(device, stream) of the context a request runs on: concurrent streams never share scratch.  `devices`: a sequence
     of GPU ordinals -> the multi-GPU context over them (params axis cut into contiguous blocks, mdt_ctx_create_multi)"""
+    if getattr(pr, "shards", None) is not None:
+        if devices is None:
+            devices = [q.device_index for q in pr.shards]
+        if [int(d) for d in devices] != [q.device_index for q in pr.shards]:
+            raise ArgumentError("block i of a pre-sharded array must live on devices[i]")
     if devices is not None:
         return tuple(int(d) for d in devices), None
     stream = torch.cuda.current_stream(pr.buf.device).cuda_stream if pr.dev else 0
@@ -262,7 +302,7 @@ def _call_ess_rhat(samples, kind, want_ess, want_rhat, relative=False, autocov_m
     if split_chains < 1:
         raise ArgumentError("split_chains must be >= 1")
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
-    pr = _prepare(samples, allow_strided=devices is None)
+    pr = _prepare(samples, allow_strided=True)
     if want_ess:
         _warn_niter(pr, split_chains)
     ess_o = _new_out(pr) if want_ess else None
@@ -340,7 +380,7 @@ def bulk_tail(samples, *, relative=False, autocov_method=None, split_chains=2, m
     split_chains = _check_int("split_chains", split_chains)
     maxlag = _check_int("maxlag", maxlag)
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
-    pr = _prepare(samples, allow_strided=devices is None)
+    pr = _prepare(samples, allow_strided=True)
     _warn_niter(pr, split_chains)
     if out is not None:
         _check_out(pr, out)
@@ -373,15 +413,16 @@ def _validate_superchain_ids(superchain_ids, nchains):
 
 def rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, devices=None):
     """Nested R-hat (src/rhat_nested.jl:43-188)."""
-    nd = samples.ndim if hasattr(samples, "ndim") else np.asarray(samples).ndim
+    first = samples[0] if _is_shard_list(samples) else samples
+    nd = first.ndim if hasattr(first, "ndim") else np.asarray(first).ndim
     if nd < 2:
         raise ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`")
     split_chains = _check_int("split_chains", split_chains)
-    inds = _validate_superchain_ids(superchain_ids, samples.shape[1])
+    inds = _validate_superchain_ids(superchain_ids, first.shape[1])
     kind = _norm_kind(kind)
     if kind not in _KINDS:
         raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat_nested`")
-    pr = _prepare(samples, allow_strided=devices is None)
+    pr = _prepare(samples, allow_strided=True)
     out = _new_out(pr)
     if pr.P > 0:
         h = _ctx_key(pr, devices)
@@ -395,17 +436,18 @@ def mcse_rhat_nested(samples, superchain_ids, *, kind="rank", split_chains=2, ma
                      devices=None):
     """(mcse(samples; kind=mean), rhat_nested(samples, superchain_ids; kind)) from ONE launch (mdt_mcse_nested): every
     parameter's slice is read from HBM once for both (BASELINE config 5).  Bit-identical to the two separate calls."""
-    nd = samples.ndim if hasattr(samples, "ndim") else np.asarray(samples).ndim
+    first = samples[0] if _is_shard_list(samples) else samples
+    nd = first.ndim if hasattr(first, "ndim") else np.asarray(first).ndim
     if nd < 2:
         raise ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`")
     split_chains = _check_int("split_chains", split_chains)
     maxlag = _check_int("maxlag", maxlag)
     autocov = _autocov_code(AutocovMethod() if autocov_method is None else autocov_method)
-    inds = _validate_superchain_ids(superchain_ids, samples.shape[1])
+    inds = _validate_superchain_ids(superchain_ids, first.shape[1])
     kind = _norm_kind(kind)
     if kind not in _KINDS:
         raise ArgumentError(f"the `kind` `{kind}` is not supported by `rhat_nested`")
-    pr = _prepare(samples, allow_strided=devices is None)
+    pr = _prepare(samples, allow_strided=True)
     _warn_niter(pr, split_chains)
     m_out, r_out = _new_out(pr), _new_out(pr)
     if pr.P > 0:
@@ -430,7 +472,7 @@ def mcse(samples, *, kind=np.mean, **kwargs):
     devices = kwargs.pop("devices", None)
     if kwargs:
         raise TypeError(f"unsupported keyword arguments {sorted(kwargs)}")
-    pr = _prepare(samples, allow_strided=devices is None)
+    pr = _prepare(samples, allow_strided=True)
     _warn_niter(pr, split_chains)
     out = _new_out(pr)
     if pr.P > 0:

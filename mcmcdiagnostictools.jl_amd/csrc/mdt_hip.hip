@@ -49,10 +49,60 @@
 #include <algorithm>
 #include <atomic>
 #include <string>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 using mdtc::KP;
+
+// worker threads of a multi-GPU context: created once, parked on a condition variable between requests
+struct MultiPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    std::function<int(int)> job; // shard index -> status
+    std::vector<int> rcs;
+    unsigned long long epoch = 0;
+    int pending = 0;
+    bool stop = false;
+    explicit MultiPool(int n) : rcs(n, MDT_OK) {
+        for (int i = 0; i < n; ++i) threads.emplace_back([this, i] { loop(i); });
+    }
+    void loop(int i) {
+        unsigned long long seen = 0;
+        for (;;) {
+            std::function<int(int)> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || epoch != seen; });
+                if (stop) return;
+                seen = epoch;
+                j = job;
+            }
+            const int rc = j(i);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                rcs[i] = rc;
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(const std::function<int(int)>& j) { // every worker runs j(its index); returns when all are back
+        std::unique_lock<std::mutex> lk(mu);
+        job = j;
+        pending = (int)threads.size();
+        ++epoch;
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~MultiPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : threads) t.join();
+    }
+};
 
 struct mdt_ctx {
     int device = 0;
@@ -75,6 +125,7 @@ struct mdt_ctx {
     long long ztab_cap = 0;
     // several GPUs of one node (mdt_ctx_create_multi): one child context per device, params cut into contiguous blocks
     std::vector<mdt_ctx*> children;
+    MultiPool* pool = nullptr;        // one worker thread per child, alive as long as the context
     // the stream the last request went to (a context serves one stream at a time; mdt_ctx_status waits on it)
     hipStream_t last_stream = nullptr;
     bool used = false;
@@ -110,6 +161,8 @@ struct mdt_ctx {
     size_t stage_x_cap = 0;
     void* stage_out = nullptr;
     size_t stage_out_cap = 0;
+    // slot k of the output staging area of a multi-GPU block of cnt values (16-byte aligned slots)
+    void* stage_out_multi(int k, long long cnt, size_t ts) const { return (char*)stage_out + (size_t)k * ((((size_t)cnt * ts) + 15) & ~(size_t)15); }
 };
 
 namespace {
@@ -477,6 +530,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         maxlag = 1;
     }
     if (!(a->tail_prob > 0.0 && a->tail_prob < 1.0) && rq.need_et) return fail(ctx, MDT_EARG, "tail_prob must be in (0, 1)");
+    if (rq.need_et && (a->tail_p_lo != 0.0 || a->tail_p_hi != 0.0) && !(a->tail_p_lo > 0.0 && a->tail_p_lo < a->tail_p_hi && a->tail_p_hi < 1.0))
+        return fail(ctx, MDT_EARG, "tail_p_lo / tail_p_hi must be both 0 or 0 < tail_p_lo < tail_p_hi < 1");
     if (rq.est == MDT_KIND_QUANTILE && !(a->tail_prob >= 0.0 && a->tail_prob <= 1.0))
         return fail(ctx, MDT_EARG, "quantile probability must be in [0, 1]"); // Statistics.quantile
     // engine limits
@@ -596,7 +651,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     for (int i = 0; i < 2; ++i) {
         long long j; double g;
         if (f32) {
-            const float p = (rq.est == MDT_KIND_QUANTILE) ? (float)a->tail_prob : ((i == 0) ? (float)(a->tail_prob / 2) : (float)(1 - a->tail_prob / 2));
+            const bool given = a->tail_p_lo != 0.0 && a->tail_p_hi != 0.0 && rq.est != MDT_KIND_QUANTILE; // (the caller's own pl, pu)
+            const float p = (rq.est == MDT_KIND_QUANTILE) ? (float)a->tail_prob
+                            : given ? (float)((i == 0) ? a->tail_p_lo : a->tail_p_hi) : ((i == 0) ? (float)(a->tail_prob / 2) : (float)(1 - a->tail_prob / 2));
             const float aleph = fmaf((float)n, p, 1.0f - p);
             j = (long long)aleph;
             if (j < 1) j = 1;
@@ -605,7 +662,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
             gg = gg < 0 ? 0 : (gg > 1 ? 1 : gg);
             g = (double)gg;
         } else {
-            const double p = (rq.est == MDT_KIND_QUANTILE) ? a->tail_prob : ((i == 0) ? (a->tail_prob / 2) : (1 - a->tail_prob / 2));
+            const bool given = a->tail_p_lo != 0.0 && a->tail_p_hi != 0.0 && rq.est != MDT_KIND_QUANTILE;
+            const double p = (rq.est == MDT_KIND_QUANTILE) ? a->tail_prob
+                             : given ? ((i == 0) ? a->tail_p_lo : a->tail_p_hi) : ((i == 0) ? (a->tail_prob / 2) : (1 - a->tail_prob / 2));
             const double aleph = fma((double)n, p, 1.0 - p);
             j = (long long)aleph;
             if (j < 1) j = 1;
@@ -648,7 +707,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.prof = ctx->prof;
     // ticket order: by the durations the previous launch with as many parameters measured; this launch measures again
     kp.order = nullptr; kp.cost = nullptr;
-    const bool lpt = P >= 4 * wgs && P < 0xFFFFFFFFLL && !getenv("MDT_NO_ORDER"); // (fewer tickets than that: there is no tail to speak of)
+    const bool lpt = P > wgs && P < 0xFFFFFFFFLL && !getenv("MDT_NO_ORDER"); // (one ticket per workgroup at most: nothing to order)
     if (lpt) {
         if (P > ctx->order_cap) {
             if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
@@ -679,7 +738,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
     if (lpt) { // (same stream: it runs when every duration is in, and before the next launch reads the order)
         // the cheapest 2 x wgs parameters close the launch in sorted order; the others are walked with a stride near head / 7.3
-        long long tail = std::min<long long>(P, 2 * wgs), head = P - tail, stride = 1;
+        // (a handful of tickets per workgroup -- BASELINE config 3 has 3.9 --: the makespan is a bin-packing problem, the whole
+        // sequence is sorted, longest first)
+        long long tail = P <= 6 * wgs ? P : std::min<long long>(P, 2 * wgs), head = P - tail, stride = 1;
         if (const char* e = getenv("MDT_ORDER_TAIL")) { tail = std::min<long long>(P, std::max<long long>(0, atoll(e))); head = P - tail; } // (A/B timing)
         if (head > 2 && !getenv("MDT_ORDER_PURE")) {
             stride = std::max<long long>(2, (long long)((double)head / 7.3));
@@ -714,70 +775,112 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     return MDT_OK;
 }
 
-// ---- several GPUs: the params axis in contiguous blocks, one host thread and one child context per device
-int run_shard(mdt_ctx* child, const mdt_args* a, const void* x, const Req& rq, long long lo, long long hi, int owner_dev) {
-    const long long n = a->draws * a->chains, cnt = hi - lo;
+// ---- several GPUs: the params axis in contiguous blocks, one worker thread and one child context per device.
+// The partition rule is ONE rule everywhere (mdt_shard_bounds, dist.shard_bounds of the Python mirror, the Julia shim): the
+// first P mod N blocks hold one parameter more.
+void shard_bounds(long long P, int i, int n, long long* lo, long long* hi) {
+    const long long q = P / n, r = P % n;
+    *lo = (long long)i * q + std::min<long long>(i, r);
+    *hi = *lo + q + (i < r ? 1 : 0);
+}
+
+// One request over the children of a multi-GPU context.  fn(child, args of the block, x of the block, outs of the block)
+// runs on the child's worker thread; this helper finds every block's input -- already on the child's GPU (pre-sharded:
+// args->x_shards, or the block of a single array that lives on that GPU), in host memory, or on another GPU (fetched by
+// one peer copy over xGMI) -- and brings the block's outputs back to the caller's vectors (written in place when they live
+// on the child's GPU or in host memory, one peer copy per output otherwise).
+constexpr int MULTI_NOUT = 6;
+using ShardFn = std::function<int(mdt_ctx*, const mdt_args*, const void*, void* const*)>;
+int for_shards(mdt_ctx* ctx, const mdt_args* a, const void* x, void* const* outs, int nout, const ShardFn& fn) {
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
+    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
+    const long long P = a->params, D = a->draws, C = a->chains;
+    if (P == 0) return MDT_OK;
+    if (!x && !a->x_shards) return fail(ctx, MDT_EARG, "x is NULL");
+    if (D == 0 || C == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+    const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : D * C;
+    if (cs < D || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
+    const int nd = (int)ctx->children.size();
     const size_t ts = tsize(a->dtype);
-    mdt_args b = *a;
-    b.params = cnt;
-    b.sync = 1;
-    const char* xs = (const char*)x + (size_t)lo * n * ts;
-    void* Req::*outs[6] = {&Req::out_eb, &Req::out_rb, &Req::out_et, &Req::out_rt, &Req::out_rrank, &Req::out_mcse};
-    Req r = rq;
-    if (a->location == MDT_HOST || child->device == owner_dev) {
-        for (auto o : outs) if (r.*o) r.*o = (char*)(r.*o) + (size_t)lo * ts;
-        if (a->location == MDT_HOST) b.stream = nullptr; // (the caller's stream belongs to one device at most)
-        return run(child, &b, xs, r);
+    // where the single array / the gathered outputs live (device memory: found from the pointers)
+    int x_dev = -1, out_dev = -1;
+    if (a->location == MDT_DEVICE) {
+        hipPointerAttribute_t at;
+        if (!a->x_shards) {
+            if (hipPointerGetAttributes(&at, x) != hipSuccess) return fail(ctx, MDT_EARG, "x is not a device pointer");
+            x_dev = at.device;
+        }
+        for (int k = 0; k < nout; ++k)
+            if (outs[k]) {
+                if (hipPointerGetAttributes(&at, outs[k]) != hipSuccess) return fail(ctx, MDT_EARG, "an output is not a device pointer");
+                out_dev = at.device;
+                break;
+            }
+        // the producers of x have finished (the caller's stream belongs to the device that is current for the caller)
+        if (hipStreamSynchronize((hipStream_t)a->stream) != hipSuccess) return fail(ctx, MDT_ERUNTIME, "cannot synchronise the stream of x");
     }
-    // the block lives on another GPU: fetch it, work on the copy, send the results back (peer copies over xGMI)
-    mdt_ctx* ctx = child;
-    MDT_ON_DEVICE(child);
-    const size_t xb = (size_t)cnt * n * ts;
-    if (int rc = stage_x_bytes(child, xb)) return rc;
-    if (int rc = stage_out_bytes(child, 6 * (size_t)cnt * ts)) return rc;
-    HIP_TRY(hipMemcpyPeer(child->stage_x, child->device, xs, owner_dev, xb));
-    int k = 0;
-    for (auto o : outs) { if (r.*o) r.*o = (char*)child->stage_out + (size_t)k * cnt * ts; ++k; }
-    b.stream = nullptr;
-    if (int rc = run(child, &b, child->stage_x, r)) return rc;
-    k = 0;
-    for (auto o : outs) {
-        if (rq.*o) HIP_TRY(hipMemcpyPeer((char*)(rq.*o) + (size_t)lo * ts, owner_dev, (char*)child->stage_out + (size_t)k * cnt * ts, child->device, (size_t)cnt * ts));
-        ++k;
-    }
+    auto job = [&](int i) -> int {
+        mdt_ctx* child = ctx->children[i];
+        long long lo, hi;
+        shard_bounds(P, i, nd, &lo, &hi);
+        const long long cnt = hi - lo;
+        if (cnt == 0) return MDT_OK;
+        mdt_args b = *a;
+        b.params = cnt;
+        b.sync = 1;
+        b.stream = nullptr; // (every child works on its own device's default stream)
+        b.x_shards = nullptr;
+        mdt_ctx* ctx = child; // (HIP_TRY reports into the child)
+        MDT_ON_DEVICE(child);
+        const void* xs;
+        if (a->x_shards) {
+            xs = a->x_shards[i];
+            if (!xs) return fail(child, MDT_EARG, "x_shards holds a NULL block");
+            if (a->location == MDT_DEVICE) {
+                hipPointerAttribute_t at;
+                if (hipPointerGetAttributes(&at, xs) != hipSuccess || at.device != child->device)
+                    return fail(child, MDT_EARG, "x_shards[i] must live on device_ids[i] of the context");
+            }
+        } else {
+            xs = (const char*)x + (size_t)lo * (size_t)ps * ts;
+            if (a->location == MDT_DEVICE && x_dev != child->device) {
+                // the block lives on another GPU: fetch its extent (whatever lies between its pieces) by one peer copy
+                const size_t xb = (size_t)((cnt - 1) * ps + (C - 1) * cs + D) * ts;
+                if (int rc = stage_x_bytes(child, xb)) return rc;
+                HIP_TRY(hipMemcpyPeer(child->stage_x, child->device, xs, x_dev, xb));
+                xs = child->stage_x;
+            }
+        }
+        void* lo_outs[MULTI_NOUT] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        const bool out_local = a->location == MDT_HOST || out_dev == child->device || out_dev < 0;
+        if (!out_local) { if (int rc = stage_out_bytes(child, (size_t)nout * cnt * ts + (size_t)MULTI_NOUT * 16)) return rc; }
+        for (int k = 0; k < nout; ++k)
+            if (outs[k]) lo_outs[k] = out_local ? (void*)((char*)outs[k] + (size_t)lo * ts)
+                                                 : (void*)((char*)child->stage_out_multi(k, cnt, ts));
+        if (int rc = fn(child, &b, xs, lo_outs)) return rc;
+        if (!out_local)
+            for (int k = 0; k < nout; ++k)
+                if (outs[k]) HIP_TRY(hipMemcpyPeer((char*)outs[k] + (size_t)lo * ts, out_dev, lo_outs[k], child->device, (size_t)cnt * ts));
+        return MDT_OK;
+    };
+    ctx->pool->run(job);
+    for (int i = 0; i < nd; ++i)
+        if (ctx->pool->rcs[i]) return fail(ctx, ctx->pool->rcs[i], "device " + std::to_string(ctx->children[i]->device) + ": " + ctx->children[i]->err);
     return MDT_OK;
 }
 
 int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq) {
-    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
-    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
-    if (a->draws < 0 || a->chains < 0 || a->params < 0) return fail(ctx, MDT_EDIM, "negative dimension");
-    if (a->chain_stride || a->param_stride) return fail(ctx, MDT_EARG, "a multi-GPU context takes the dense layout only");
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
     if ((rq.mode > 2 && rq.mode != 4 && rq.mode != 6) || rq.tpos_arr) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
-    const long long P = a->params;
-    if (P == 0) return MDT_OK;
-    if (!x) return fail(ctx, MDT_EARG, "x is NULL");
-    const int nd = (int)ctx->children.size();
-    int owner_dev = -1;
-    if (a->location == MDT_DEVICE) {
-        hipPointerAttribute_t at;
-        if (hipPointerGetAttributes(&at, x) != hipSuccess) return fail(ctx, MDT_EARG, "x is not a device pointer");
-        owner_dev = at.device;
-        DeviceGuard g(owner_dev);
-        if (!g.ok || hipStreamSynchronize((hipStream_t)a->stream) != hipSuccess) // the producers of x have finished
-            return fail(ctx, MDT_ERUNTIME, "cannot synchronise the stream of x");
-    }
-    std::vector<int> rcs(nd, MDT_OK);
-    std::vector<std::thread> th;
-    for (int i = 0; i < nd; ++i) {
-        const long long lo = (long long)i * P / nd, hi = (long long)(i + 1) * P / nd;
-        if (hi == lo) continue;
-        th.emplace_back([=, &rcs, &rq] { rcs[i] = run_shard(ctx->children[i], a, x, rq, lo, hi, owner_dev); });
-    }
-    for (auto& t : th) t.join();
-    for (int i = 0; i < nd; ++i)
-        if (rcs[i]) return fail(ctx, rcs[i], "device " + std::to_string(ctx->children[i]->device) + ": " + ctx->children[i]->err);
-    return MDT_OK;
+    void* Req::*slots[MULTI_NOUT] = {&Req::out_eb, &Req::out_rb, &Req::out_et, &Req::out_rt, &Req::out_rrank, &Req::out_mcse};
+    void* outs[MULTI_NOUT];
+    for (int k = 0; k < MULTI_NOUT; ++k) outs[k] = rq.*slots[k];
+    return for_shards(ctx, a, x, outs, MULTI_NOUT, [&](mdt_ctx* child, const mdt_args* b, const void* xs, void* const* lo_outs) {
+        Req r = rq;
+        for (int k = 0; k < MULTI_NOUT; ++k) r.*slots[k] = lo_outs[k];
+        return run(child, b, xs, r);
+    });
 }
 
 } // namespace
@@ -837,6 +940,7 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
 int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (!ctx) return MDT_OK;
     if (!ctx->children.empty()) {
+        delete ctx->pool; // (joins the worker threads)
         for (mdt_ctx* c : ctx->children) (void)mdt_ctx_destroy(c);
         delete ctx;
         return MDT_OK;
@@ -899,7 +1003,17 @@ int mdt_ctx_create_multi(mdt_ctx** out, const int* device_ids, int ndev) {
         }
         (void)hipGetLastError();
     }
+    ctx->pool = new (std::nothrow) MultiPool(ndev);
+    if (!ctx->pool) { for (mdt_ctx* d : ctx->children) (void)mdt_ctx_destroy(d); delete ctx; return MDT_ENOMEM; }
     *out = ctx;
+    return MDT_OK;
+}
+
+int mdt_shard_bounds(int64_t params, int32_t shard, int32_t nshards, int64_t* lo, int64_t* hi) {
+    if (!lo || !hi || nshards < 1 || shard < 0 || shard >= nshards || params < 0) return MDT_EARG;
+    long long l, h;
+    shard_bounds(params, shard, nshards, &l, &h);
+    *lo = l; *hi = h;
     return MDT_OK;
 }
 
@@ -1042,9 +1156,14 @@ int mdt_mcse_std(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out)
 
 int mdt_mcse_quantile(mdt_ctx* ctx, const mdt_args* a, const void* x, void* mcse_out) {
     if (!ctx) return MDT_EARG;
-    if (!ctx->children.empty()) return fail(ctx, MDT_EUNSUPPORTED, "this entry point does not run on a multi-GPU context");
     if (!a) return fail(ctx, MDT_EARG, "args is NULL");
     if (!mcse_out) return fail(ctx, MDT_EARG, "NULL output");
+    if (!ctx->children.empty()) { // every block runs its two passes on its own GPU
+        void* outs[1] = {mcse_out};
+        return for_shards(ctx, a, x, outs, 1, [](mdt_ctx* child, const mdt_args* b, const void* xs, void* const* lo_outs) {
+            return mdt_mcse_quantile(child, b, xs, lo_outs[0]);
+        });
+    }
     if (a->kind != MDT_KIND_MEDIAN && a->kind != MDT_KIND_QUANTILE)
         return fail(ctx, MDT_EARG, "mdt_mcse_quantile: kind must be MDT_KIND_MEDIAN or MDT_KIND_QUANTILE");
     const long long P = a->params, n = a->draws * a->chains;

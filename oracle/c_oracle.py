@@ -115,6 +115,25 @@ def bulk_tail(x, autocov="direct", split_chains=2, maxlag=250, relative=False, t
     return tuple(outs)
 
 
+def bulk_tail_all_cores(x, autocov="direct", split_chains=2, maxlag=250, tail_prob=0.1, nthreads=0, chunk=8):
+    """bulk_tail over an OpenMP team: blocks of `chunk` parameters per thread (the all-core CPU baseline of bench.py).
+    Float64 only.  Returns (ess_bulk, ess_tail, rhat_bulk, rhat_tail), the same numbers as bulk_tail."""
+    x = _as3d(x)
+    assert x.dtype == np.float64
+    a = _args(x, "bulk", autocov, split_chains, maxlag, False, tail_prob)
+    P = x.shape[2]
+    outs = [np.empty(P, np.float64) for _ in range(4)]
+    f = lib().mdt_oracle_bulk_tail_omp_f64
+    rc = f(ctypes.byref(a), _ptr(x), *[_ptr(o) for o in outs], ctypes.c_int(int(nthreads)), ctypes.c_int64(int(chunk)))
+    if rc:
+        raise OracleError(rc)
+    return tuple(outs)
+
+
+def omp_threads():
+    return int(lib().mdt_oracle_omp_threads())
+
+
 def rhat_nested(x, chain_inds, kind="rank", split_chains=2, faithful=False):
     """chain_inds: (K, S) int array, 0-based; column k lists the chains of superchain k."""
     x = _as3d(x)

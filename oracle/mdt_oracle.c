@@ -181,3 +181,53 @@ static double mdto_betainvcdf(double a, double b, double p) {
 #undef A
 #undef SFX
 #undef T_IS_DOUBLE
+
+
+/*
+ * The same oracle on all host cores (bench.py's `cpu_baseline_all_cores`): the parameters are
+ * independent (the `for` over _eachparam, src/ess_rhat.jl:517), so blocks of `chunk` parameters go to the threads of an
+ * OpenMP team, each block through the single-threaded functions above on its own sub-array (the params axis is the
+ * slowest, a block is contiguous).  The reference itself is single-threaded: this is the generous baseline, the
+ * single-core figure stays the contractual one.
+ */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include <malloc.h>
+int mdt_oracle_bulk_tail_omp_f64(const mdt_oracle_args* a, const double* x, double* ess_bulk, double* ess_tail,
+                                 double* rhat_bulk, double* rhat_tail, int nthreads, int64_t chunk) {
+    const int64_t P = a->params, n = a->draws * a->chains;
+    if (chunk < 1) chunk = 1;
+    const int64_t nblk = (P + chunk - 1) / chunk;
+    int rc_all = 0;
+    /* every block allocates and frees slice-sized temporaries: keep them in the thread arenas instead of mapping and
+     * unmapping pages on every call (hundreds of threads faulting fresh pages serialise in the kernel) */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20); /* (glibc's ceiling: HEAP_MAX_SIZE / 2; a block's largest temporary is a few MB) */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+#endif
+    for (int64_t b = 0; b < nblk; ++b) {
+        const int64_t p0 = b * chunk, cnt = (p0 + chunk <= P) ? chunk : P - p0;
+        mdt_oracle_args s = *a;
+        s.params = cnt;
+        const int rc = mdt_oracle_bulk_tail_f64(&s, x + p0 * n, ess_bulk + p0, ess_tail + p0, rhat_bulk + p0, rhat_tail + p0);
+        if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            rc_all = rc;
+        }
+    }
+    return rc_all;
+}
+
+int mdt_oracle_omp_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

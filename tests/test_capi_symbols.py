@@ -32,13 +32,13 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.mdt_version.restype = ctypes.c_int
-    assert lib.mdt_version() == 200
+    assert lib.mdt_version() == 300
 
 
 def test_struct_layout_matches_header():
     pkg = g.load_package()
-    # int64 x3, int32 x8, int64, double, void*, int64 x2 : 24 + 32 + 8 + 8 + 8 + 16
-    assert ctypes.sizeof(pkg._lib.MdtArgs) == 96
+    # int64 x3, int32 x8, int64, double, void*, int64 x2, void**, double x2 : 24 + 32 + 8 + 8 + 8 + 16 + 8 + 16
+    assert ctypes.sizeof(pkg._lib.MdtArgs) == 120
 
 
 def test_product_does_not_touch_the_oracle():

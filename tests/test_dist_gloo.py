@@ -51,3 +51,25 @@ def test_sharded_gather_world2(tmp_path, P):
     mp.spawn(_worker, args=(2, port, P, path), nprocs=2, join=True)
     for r in range(2):
         assert open(f"{path}.{r}").read() == "ok"
+
+
+def test_one_partition_rule():
+    """the C-ABI's block rule (mdt_shard_bounds: what a multi-GPU context cuts by, and what a caller with pre-sharded
+    input must follow) is dist.shard_bounds (what the one-process-per-GPU path cuts by): first P mod N blocks one longer.
+    Pure arithmetic in the library: runs without a GPU."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    lib = pkg._lib.load()
+    for P in (0, 1, 7, 8, 10_000, 1_000_003):
+        for n in (1, 2, 3, 8):
+            prev = 0
+            for i in range(n):
+                lo, hi = ctypes.c_int64(), ctypes.c_int64()
+                assert lib.mdt_shard_bounds(P, i, n, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == pkg.shard_bounds(P, i, n)
+                assert lo.value == prev and hi.value - lo.value in (P // n, P // n + 1)
+                prev = hi.value
+            assert prev == P
+    assert lib.mdt_shard_bounds(5, 2, 2, ctypes.byref(lo), ctypes.byref(hi)) == pkg._lib.MDT_EARG
