@@ -442,7 +442,15 @@ def main():
         # the same oracle on all host cores: an OpenMP team inside the oracle (oracle/mdt_oracle.c, mdt_oracle_bulk_tail_omp_f64),
         # blocks of 8 parameters handed out dynamically, at least 64 parameters per thread or the whole array
         try:
-            ncore = len(os.sched_getaffinity(0))
+            nvis = len(os.sched_getaffinity(0))
+            ncore, quota_note = nvis, ""
+            try:  # the container's CPU quota (cgroup v2 cpu.max = "<quota> <period>"): more threads than that only throttle each other
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+                if q != "max":
+                    ncore = max(1, min(nvis, int(int(q) // int(per))))
+                    quota_note = f"; the box shows {nvis} hardware threads but its cgroup cpu.max grants {int(q) / int(per):g} CPUs: one thread per granted CPU"
+            except Exception:
+                pass
             if ncore > 1:
                 nall = int(min(P, max(64 * ncore, ns)))
                 sel_all = np.arange(P) if nall == P else np.linspace(0, P - 1, nall).astype(np.int64)
@@ -460,7 +468,7 @@ def main():
                 res["cpu_baseline_all_cores"] = {
                     "value": nall / tall, "unit": "param-series/s", "cores": ncore, "kind": "port",
                     "sample": f"{nall} of the {P} parameters of the same array ({nall // ncore} per thread), OpenMP parallel for over blocks of 8 "
-                              f"parameters inside oracle/mdt_oracle.c, {ncore} threads, {tall:.1f} s",
+                              f"parameters inside oracle/mdt_oracle.c, {ncore} threads, {tall:.1f} s" + quota_note,
                     "scaling_vs_1core": (nall / tall) / res["cpu_baseline"]["value"],
                     "parity_max_rel_err_vs_oracle": errA,
                 }

@@ -550,7 +550,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
     const bool fft_lds = fft && getenv("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
-                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * 64;
+                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * (getenv("MDT_SMALL_ROUNDS") ? atoll(getenv("MDT_SMALL_ROUNDS")) : 64);
     // short slices: four 256-thread workgroups per CU (40 KiB of LDS each) -- a parameter of a few thousand values
     // is mostly barrier and latency chains, which twice as many resident workgroups hide twice as well
     int force_cfg = ctx->force_cfg; // MDT_CONFIG is honoured per request (tests switch it between calls)
