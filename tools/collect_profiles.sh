@@ -2,7 +2,7 @@
 # Collect the round's evidence on the GPU box: bench line (headline + other_configs), rocprofv3 kernel stats of the same
 # command, calibrated PMC traffic for the three measured workloads, per-phase cycle tables.
 # usage (inside gpurun): bash tools/collect_profiles.sh <tag>      then, back home: python tools/summarize_profiles.py <tag>
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 MDT_PROF=1 python tools/phase_profile.py --params 10000 > $O/phase_cfg2.txt 2>/dev/null
@@ -11,6 +11,7 @@ MDT_PROF=1 python tools/phase_profile.py --params 1000 --draws 100000 --chains 8
 [ -f tools/exp/libproff.so ] && MDT_LIB=$R/tools/exp/libproff.so MDT_PROF=1 python tools/phase_profile.py --params 10000 --f > $O/phase_cfg2_fold.txt 2>/dev/null
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
+bash tools/pmc_sq.sh > $O/sq_counters.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null
 for cfg in cfg2:10000 cfg3:1000 cfg5:12500; do
@@ -21,3 +22,14 @@ done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_cal -- $R/tools/scatter_bench > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_cal -- $R/tools/scatter_bench > /dev/null 2>&1
 cat $O/bench.json
+# keep the merge-back small (64 MiB): of every CSV only the rows of this library's kernels (the synthetic-input generator
+# launches thousands of torch kernels), nothing else of rocprofv3's output
+prune() {
+  find "$1" -type f ! -name "*.csv" ! -name "*.txt" ! -name "*.json" ! -name "*.err" ! -name "*.log" -delete 2>/dev/null
+  for f in $(find "$1" -type f -name "*.csv"); do
+    case "$f" in *kernel_stats.csv|*agent_info.csv) continue;; esac
+    head -1 "$f" > "$f.tmp"; grep -E "mdt_|copy8|order_kernel|kp_setup" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"
+  done
+}
+prune $O; prune $R/gpurun_out/sq
+du -sh $R/gpurun_out 1>&2

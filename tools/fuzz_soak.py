@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Soak test (needs a GPU; not part of the pytest suite): random shapes up to ~150 000 values per slice, splits,
-kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many]
-(long: chains of 50 000 - 131 072 draws; many: 100 - 1500 chains, more split chains than the LDS moment tables hold)"""
+kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many|order]
+(long: chains of 50 000 - 131 072 draws; many: 100 - 1500 chains, more split chains than the LDS moment tables hold;
+order: 600 - 4000 short parameters per request, each request issued twice -- the second launch hands its tickets out by
+the costs the first one measured.  Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,6 +18,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
 MANY = len(sys.argv) > 3 and sys.argv[3] == "many"
+ORDER = len(sys.argv) > 3 and sys.argv[3] == "order"
 methods = {"direct": pkg.AutocovMethod(), "fft": pkg.FFTAutocovMethod(), "bda": pkg.BDAAutocovMethod()}
 
 
@@ -41,7 +44,13 @@ while time.time() - t0 < budget:
     if MANY:  # many short chains (one thread per split chain)
         C = int(rng.integers(100, 1500))
         D, P = int(rng.integers(6, max(7, min(400, 150000 // C)))), int(rng.integers(1, 3))
+    if ORDER:  # many short parameters: more tickets than workgroups, the second launch is cost-ordered
+        D, C, P = int(rng.integers(20, 400)), int(rng.integers(1, 5)), int(rng.integers(600, 4000))
     s = int(rng.integers(1, 4))
+    if it % 2:
+        os.environ["MDT_PA"] = "2"
+    else:
+        os.environ.pop("MDT_PA", None)
     fl = ("normal", "ar", "ties", "skew", "offset", "mass")[it % 6]
     if fl == "normal":
         x = rng.standard_normal((D, C, P))
@@ -76,10 +85,11 @@ while time.time() - t0 < budget:
             We, Wr = co.ess_rhat(x, kind=kind, autocov=m, split_chains=s, maxlag=ml)
             assert_close(host(S), We, tol, what + f" ess {kind}")
             assert_close(host(R), Wr, tol, what + f" rhat {kind}")
-        eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
         wb = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml)
-        for a, b in zip((eb, et, rb, rt), wb):
-            assert_close(host(a), b, tol, what + " fused")
+        for rep in range(2 if ORDER else 1):
+            eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
+            for a, b in zip((eb, et, rb, rt), wb):
+                assert_close(host(a), b, tol, what + f" fused (launch {rep + 1})")
         for est, kind in (("median", np.median), ("mad", "mad")):
             got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             assert_close(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), tol, what + " " + est)
@@ -88,5 +98,10 @@ while time.time() - t0 < budget:
             got = pkg.rhat_nested(xd, ids, kind="rank", split_chains=s)
             K, S2 = 2, C // 2
             inds = np.arange(C, dtype=np.int32).reshape(S2, K).T.copy()
-            assert_close(host(got), co.rhat_nested(x, inds, kind="rank", split_chains=s), tol, what + " nested")
+            want_n = co.rhat_nested(x, inds, kind="rank", split_chains=s)
+            assert_close(host(got), want_n, tol, what + " nested")
+            if D // s > 4:  # the fused request: mcse(mean) + nested R-hat from one launch
+                mm, rr = pkg.mcse_rhat_nested(xd, ids, kind="rank", split_chains=s, maxlag=ml, autocov_method=methods[m])
+                assert_close(host(rr), want_n, tol, what + " fused nested")
+                assert_close(host(mm), co.mcse_mean(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " fused mcse")
 print(f"fuzz soak: {it} random requests x 8-9 calls each agreed with the oracle in {time.time() - t0:.0f} s")

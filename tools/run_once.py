@@ -21,8 +21,7 @@ elif cfg == "cfg5":
     x = synth_cfg5(10000, 16, P, dev, 55).permute(2, 1, 0)
     ids = np.repeat(np.arange(1, 5), 4)
     for _ in range(reps):
-        pkg.mcse(x)
-        pkg.rhat_nested(x, ids, kind="rank")
+        pkg.mcse_rhat_nested(x, ids, kind="rank")   # one fused launch (mdt_mcse_nested)
 else:
     x = synth(10000, 4, P, dev, 1234).permute(2, 1, 0)
     for _ in range(reps):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), f"profiles/{tag}_bench.json")
@@ -61,7 +61,7 @@ for d, key in (("pmc_fetch_cal", "fetch"), ("pmc_write_cal", "write")):
     known_kb = 256 * 40000 * 8 * 20 / 1024
     cal[key] = sum(float(r["Counter_Value"]) for r in rs) / len(rs) / known_kb
 WORK = {"cfg2": (10000, 4, 10000, 8, 1, "mdt_small::mdt_kernel<double>"), "cfg3": (100000, 8, 1000, 8, 1, "mdt_big::mdt_kernel<double>"),
-        "cfg5": (10000, 16, 12500, 4, 2, "mdt_small::mdt_kernel<float> (mcse(mean) + rhat_nested(rank): two launches)")}
+        "cfg5": (10000, 16, 12500, 4, 1, "mdt_small::mdt_kernel<float> (mcse(mean) + rhat_nested(rank): one fused launch, mdt_mcse_nested)")}
 out = {"calibration": {"fetch_counter_over_known": cal["fetch"], "write_counter_over_known": cal["write"],
                        "how": "same session, tools/scatter_bench copy8 (8 B/lane coalesced, 256 WG x 1024 threads, 6.55 GB known each way)"},
        "note": "memory-side (L2<->fabric) bytes; Infinity-Cache hits are included (upper bound on HBM traffic)"}
