@@ -636,7 +636,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // for, the one-chain-per-LDS-buffer sweep when a split chain fits, the tiled series_phase otherwise
             const bool acov = r_need_eb && kp.ess_ok;
             if (many) { // more split chains than the moment tables hold: one thread per split chain (many_phase)
-                const SeriesOut sm = many_phase(kp, YX, xs, acov, smem);
+                const SeriesOut sm = many_phase(kp, YX, xs, acov, smem, rmode == 1 ? 1 : 0);
                 const double ess = acov ? sm.ess : nan;
                 if (rmode == 2) { // pooled corrected std over all draws and chains (src/mcse.jl:50), two passes
                     double loc = 0.0;
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // the moments of a z-series always come from series_z_phase (fixed point): R-hat is the same
             // bits whichever autocovariance path follows
             if (many) { // time-order scores, one thread per split chain
-                so = many_phase(kp, YZ, xs, acov, smem);
+                so = many_phase(kp, YZ, xs, acov, smem, nested ? 1 : 0);
             } else if (rk == 4) { // long chains: moments from the ranking, lag products from its windowed score layout
                 bits_done = zq_ok && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
                 so = series_win_phase(kp, zb, pbuf, bb, smem, bits_done ? gb : nullptr, zq[0], zq[1]);
@@ -916,7 +916,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // R-hat of the folded scores needs the split-chain moments only: the two-level ranking delivers them
             // itself (rk == 3, no score was ever written); otherwise one streaming sweep over the scores
             if (many) {
-                rt = many_phase(kp, YZ, xs, false, smem).rhat;
+                rt = many_phase(kp, YZ, xs, false, smem, nested ? 1 : 0).rhat;
             } else if (rk == 3) {
                 if (tid == 0) series_combine(kp, smem, 0, 1, false);
                 __syncthreads();

@@ -560,6 +560,16 @@ def test_fused_mcse_and_nested_rhat(pkg):
             assert np.array_equal(host(r), host(r2), equal_nan=True), (shape, kind, "nested bits")
             assert_close(host(m), c_oracle.mcse_mean(x), 1e-6, f"{shape} mcse")
             assert_close(host(r), c_oracle.rhat_nested(x, inds, kind=kind), 1e-6, f"{shape} nested {kind}")
+    # more split chains than the moment tables hold (one thread per split chain): found by the round-3 soak -- the nested
+    # combination was skipped there in the fused mode
+    xm = ar1(0.4, 63, 410, 2, rng)
+    idm = np.repeat(np.arange(2), 205)
+    indm = np.arange(410, dtype=np.int32).reshape(2, 205).T.copy()
+    for kind in KINDS:
+        m, r = pkg.mcse_rhat_nested(dev(xm), idm, kind=kind, split_chains=1)
+        assert np.array_equal(host(r), host(pkg.rhat_nested(dev(xm), idm, kind=kind, split_chains=1))), kind
+        assert np.array_equal(host(m), host(pkg.mcse(dev(xm), split_chains=1))), kind
+        assert_close(host(r), c_oracle.rhat_nested(xm, indm, kind=kind, split_chains=1), 1e-8, f"many chains nested {kind}")
     # host memory, and the errors of the two functions it fuses
     x = ar1(0.3, 200, 16, 3, rng)
     m, r = pkg.mcse_rhat_nested(x, ids)
