@@ -187,6 +187,11 @@ enum { PH_LOAD = 0, PH_RANKX = 1, PH_SERB = 2, PH_RANKF = 3, PH_SERT = 4, PH_IND
 #define MDT_PROF_FMARK(slot)
 #define MDT_PROF_QSEL(a, b) (a)
 #endif
+#if defined(MDT_STOP_AFTER) /* diagnostics build (tools/pmc_phases.sh): the ticket ends after phase k -- counters per phase by difference */
+#define MDT_STOP(k) if (MDT_STOP_AFTER == (k)) { __syncthreads(); continue; }
+#else
+#define MDT_STOP(k)
+#endif
 #define MDT_PROF_MARK(slot)                                                                   \
     do {                                                                                      \
         if (kp.prof && threadIdx.x == 0) {                                                    \
@@ -765,6 +770,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         // the ranking left the slice sorted, tags in sorted order, no NaN (rank_phase_q, srt)
         const bool sorted_ok = need_rank_x && kp.rank_variant == 2 && rk != 0 && uni(((int*)(smem + OFF_INTS))[18]) != 0;
         MDT_PROF_MARK(PH_RANKX);
+        MDT_STOP(1)
+        MDT_STOP(10)
         if (kp.mode == 5) { // _mcse_quantile (src/mcse.jl:109-117): half the distance of two order statistics, in T
             if (tid == 0) store_out<T>(kp.out_eb, p, (double)(T)(((T)ostat[1] - (T)ostat[0]) / (T)2));
             __syncthreads();
@@ -908,6 +915,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             if (nested && !many) rb = nested_combine_wg(kp, mean_j, var_j, smem);
         }
         MDT_PROF_MARK(PH_SERB);
+        MDT_STOP(2)
         if (kp.need_rt) {
             rk = 0;
             if (sorted_ok && (medT - medT == (T)0)) rk = fold_merge_phase<T>(kp, medT, n, smem, xs, bs, bb);
@@ -928,6 +936,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             if (nested && !many) rt = nested_combine_wg(kp, mean_j, var_j, smem);
             MDT_PROF_MARK(PH_SERT);
         }
+        MDT_STOP(3)
         if (kp.need_et && kp.ess_ok) {
             if (qloT != qloT || qhiT != qhiT) { et = nan; if (tid == 0) atomicOr(kp.status, 2); }
             else if (many) { // min over the two tails of the basic ESS of the indicator (src/ess_rhat.jl:301-311)
