@@ -109,8 +109,11 @@ while time.time() - t0 < budget:
         for kind in ("rank", "bulk", "tail", "basic"):
             S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             We, Wr = co.ess_rhat(x, kind=kind, autocov=m, split_chains=s, maxlag=ml)
-            check(host(S), We, tol, what + f" ess {kind}", disc or (short and kind == "tail"), short)
-            assert_close(host(R), Wr, tol, what + f" rhat {kind}")
+            # (kind = basic on the 1e6-offset flavour works on the raw draws: one ulp of a value is 1.2e-10 of the signal, and
+            # the ratio of lag sums amplifies that -- 2e-8 seen once in 918 short parameters; BASELINE's tolerance is 1e-6)
+            tk = max(tol, 1e-6) if (fl == "offset" and kind == "basic") else tol
+            check(host(S), We, tk, what + f" ess {kind}", disc or (short and kind == "tail"), short)
+            assert_close(host(R), Wr, tk, what + f" rhat {kind}")
         wb = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml)
         for rep in range(2 if ORDER else 1):
             eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
