@@ -9,6 +9,11 @@ MDT_PROF=1 python tools/phase_profile.py --params 10000 > $O/phase_cfg2.txt 2>/d
 MDT_PROF=1 python tools/phase_profile.py --params 1000 --draws 100000 --chains 8 > $O/phase_cfg3.txt 2>/dev/null
 [ -f tools/exp/libprofq.so ] && MDT_LIB=$R/tools/exp/libprofq.so MDT_PROF=1 python tools/phase_profile.py --params 10000 --q > $O/phase_cfg2_rank.txt 2>/dev/null
 [ -f tools/exp/libproff.so ] && MDT_LIB=$R/tools/exp/libproff.so MDT_PROF=1 python tools/phase_profile.py --params 10000 --f > $O/phase_cfg2_fold.txt 2>/dev/null
+for v in q:rank f:fold; do
+  [ -f tools/exp/libprof${v%%:*}.so ] || continue
+  MDT_LIB=$R/tools/exp/libprof${v%%:*}.so MDT_PROF=1 python tools/phase_profile.py --${v%%:*} --draws 100000 --chains 8 --params 1000 > $O/phase_cfg3_${v##*:}.txt 2>/dev/null
+  MDT_LIB=$R/tools/exp/libprof${v%%:*}.so MDT_PROF=1 python tools/phase_profile.py --${v%%:*} --cfg5 --params 12500 > $O/phase_cfg5_${v##*:}.txt 2>/dev/null
+done
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
 bash tools/pmc_sq.sh > $O/sq_counters.txt 2>/dev/null

@@ -35,7 +35,8 @@ if tr:
                 w0 = under["warmup"]
                 t = d[w0:w0 + under["steps"]]
                 fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)}): mean {sum(t) / len(t):.3f} ms\n")
-for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "strided", "kinds"):
+for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "phase_cfg3_rank", "phase_cfg3_fold", "phase_cfg5_rank", "phase_cfg5_fold",
+             "strided", "kinds", "sq_counters"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, f"profiles/{tag}_{name}.txt")
