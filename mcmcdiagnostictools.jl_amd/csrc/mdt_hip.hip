@@ -159,6 +159,9 @@ struct mdt_ctx {
     // host staging
     void* stage_x = nullptr;
     size_t stage_x_cap = 0;
+    // host buffers handed over in blocks of the params axis (run_host_blocks): copies on their own stream, one event per block
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev[16] = {};
     void* stage_out = nullptr;
     size_t stage_out_cap = 0;
     // slot k of the output staging area of a multi-GPU block of cnt values (16-byte aligned slots)
@@ -502,6 +505,8 @@ struct Req {
 };
 
 int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq);
+int run_host_blocks(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq, int nb);
+void shard_bounds(long long P, int i, int n, long long* lo, long long* hi);
 
 int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (!ctx) return MDT_EARG;
@@ -521,6 +526,18 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : n;
     if (cs < D || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
     const bool strided = !(cs == D && ps == n);
+    // a host buffer of some size whose parameters are contiguous pieces (params outermost): the params axis goes to the
+    // device in blocks, block i + 1 over PCIe while block i computes (the stage request returns arrays of the size of x:
+    // not this way)
+    if (a->location == MDT_HOST && rq.mode != 3 && ps >= (C - 1) * cs + D) {
+        const char* emin = getenv("MDT_HOST_PIPE_MIN"); // bytes (tests: 1)
+        const char* eblk = getenv("MDT_HOST_PIPE_BLOCKS");
+        const size_t xb = (size_t)((P - 1) * ps + (C - 1) * cs + D) * tsize(a->dtype);
+        const size_t min_bytes = emin ? (size_t)atoll(emin) : ((size_t)128 << 20);
+        long long nb = eblk ? atoll(eblk) : (long long)(xb / ((size_t)192 << 20));
+        nb = std::max<long long>(2, std::min<long long>(16, nb));
+        if (xb >= min_bytes && P >= 2 * nb && min_bytes > 0) return run_host_blocks(ctx, a, x, rq, (int)nb);
+    }
     const int ess_ok = niter > 4;
     long long maxlag = a->maxlag;
     if (rq.want_ess && ess_ok) {
@@ -775,6 +792,59 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     return MDT_OK;
 }
 
+// ---- a host buffer in blocks of the params axis: the copy of block i + 1 (own stream) overlaps the launch of block i.
+// Every block is an ordinary device-resident request on the staged copy (same strides, outputs into the staging area);
+// the status flags accumulate over the blocks and are reported once, like the plain path does.
+int run_host_blocks(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq, int nb) {
+    MDT_ON_DEVICE(ctx);
+    hipStream_t st = (hipStream_t)a->stream;
+    const size_t ts = tsize(a->dtype);
+    const long long D = a->draws, C = a->chains, P = a->params;
+    const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : D * C;
+    if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    const size_t xb = (size_t)((P - 1) * ps + (C - 1) * cs + D) * ts;
+    if (int rcs = stage_x_bytes(ctx, xb)) return rcs;
+    constexpr int NOUT = 6;
+    if (int rcs = stage_out_bytes(ctx, NOUT * (size_t)P * ts)) return rcs;
+    if (!ctx->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    void* outs_host[NOUT] = {rq.out_eb, rq.out_rb, rq.out_et, rq.out_rt, rq.out_rrank, rq.out_mcse};
+    bool first = true;
+    for (int b = 0; b < nb; ++b) {
+        long long lo, hi;
+        shard_bounds(P, b, nb, &lo, &hi);
+        const long long cnt = hi - lo;
+        if (cnt == 0) continue;
+        if (!ctx->copy_ev[b]) HIP_TRY(hipEventCreateWithFlags(&ctx->copy_ev[b], hipEventDisableTiming));
+        const size_t off = (size_t)lo * (size_t)ps * ts, bytes = (size_t)((cnt - 1) * ps + (C - 1) * cs + D) * ts;
+        HIP_TRY(hipMemcpyAsync((char*)ctx->stage_x + off, (const char*)x + off, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+        HIP_TRY(hipEventRecord(ctx->copy_ev[b], ctx->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->copy_ev[b], 0));
+        mdt_args ab = *a;
+        ab.location = MDT_DEVICE;
+        ab.params = cnt;
+        ab.sync = 0;
+        Req rb = rq;
+        void** outs_b[NOUT] = {&rb.out_eb, &rb.out_rb, &rb.out_et, &rb.out_rt, &rb.out_rrank, &rb.out_mcse};
+        for (int i = 0; i < NOUT; ++i)
+            *outs_b[i] = outs_host[i] ? (void*)((char*)ctx->stage_out + ((size_t)i * P + (size_t)lo) * ts) : nullptr;
+        if (rq.tpos_arr) rb.tpos_arr = rq.tpos_arr + 2 * lo;
+        rb.keep_status = first ? rq.keep_status : 1;
+        first = false;
+        if (int rc = run(ctx, &ab, (const char*)ctx->stage_x + off, rb)) return rc;
+    }
+    for (int i = 0; i < NOUT; ++i)
+        if (outs_host[i]) HIP_TRY(hipMemcpyAsync(outs_host[i], (char*)ctx->stage_out + (size_t)i * P * ts, (size_t)P * ts, hipMemcpyDeviceToHost, st));
+    int status = 0;
+    HIP_TRY(hipMemcpyAsync(&status, ctx->status, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (status & 3) { // reported here: not left behind as a sticky flag
+        HIP_TRY(hipMemsetAsync(ctx->status, 0, sizeof(int), st));
+        if (status & 1) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
+        return fail(ctx, MDT_EARG, "quantiles are undefined for collections containing NaNs"); // Statistics.quantile
+    }
+    return MDT_OK;
+}
+
 // ---- several GPUs: the params axis in contiguous blocks, one worker thread and one child context per device.
 // The partition rule is ONE rule everywhere (mdt_shard_bounds, dist.shard_bounds of the Python mirror, the Julia shim): the
 // first P mod N blocks hold one parameter more.
@@ -959,6 +1029,8 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
     if (ctx->ess_tmp) (void)hipFree(ctx->ess_tmp);
     if (ctx->tpos_arr) (void)hipFree(ctx->tpos_arr);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    for (hipEvent_t e : ctx->copy_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->stage_x) (void)hipFree(ctx->stage_x);
     if (ctx->stage_out) (void)hipFree(ctx->stage_out);
     if (ctx->mom) (void)hipFree(ctx->mom);

@@ -377,6 +377,48 @@ def test_estimators_from_host_memory(pkg):
         assert_close(pkg.mcse(x, kind=pkg.Quantile(0.25)), g["mcseq|quantile|0.25"], RTOL64, "mcse q host")
 
 
+def test_host_buffers_in_blocks(pkg, monkeypatch):
+    """a host buffer of some size goes to the device in blocks of the params axis, copy of block i + 1 under the launch of
+    block i (run_host_blocks); forced here on small arrays: every entry point returns the bits of the device-resident
+    request, the status flags of any block are reported, uneven blocks and Float32 included"""
+    import warnings
+    rng = np.random.default_rng(77)
+    D, C, P = 300, 4, 37
+    x = ar1(0.5, D, C, P, rng) + 0.1 * rng.standard_normal((1, C, P))
+    ids = np.array([1, 1, 2, 2])
+    monkeypatch.setenv("MDT_HOST_PIPE_MIN", "1")
+    monkeypatch.setenv("MDT_HOST_PIPE_BLOCKS", "3")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for xx in (x, x.astype(np.float32)):
+            xd = dev(xx)
+            for a, b in zip(pkg.bulk_tail(xx), pkg.bulk_tail(xd)):
+                assert np.array_equal(host(a), host(b))
+            for kind in KINDS:
+                (e1, r1), (e2, r2) = pkg.ess_rhat(xx, kind=kind), pkg.ess_rhat(xd, kind=kind)
+                assert np.array_equal(host(e1), host(e2)) and np.array_equal(host(r1), host(r2)), kind
+            assert np.array_equal(host(pkg.rhat_nested(xx, ids)), host(pkg.rhat_nested(xd, ids)))
+            assert np.array_equal(host(pkg.mcse(xx)), host(pkg.mcse(xd)))
+            m1, n1 = pkg.mcse_rhat_nested(xx, ids)
+            m2, n2 = pkg.mcse_rhat_nested(xd, ids)
+            assert np.array_equal(host(m1), host(m2)) and np.array_equal(host(n1), host(n2))
+            for kind in (np.median, np.std, "mad", pkg.Quantile(0.3)):
+                assert np.array_equal(host(pkg.ess(xx, kind=kind)), host(pkg.ess(xd, kind=kind))), kind
+            for kind in (np.std, np.median):
+                assert np.array_equal(host(pkg.mcse(xx, kind=kind)), host(pkg.mcse(xd, kind=kind))), kind
+        # a NaN in the LAST block: Statistics.quantile's ArgumentError is still reported (the flags accumulate over the blocks)
+        xn = x.copy()
+        xn[5, 1, P - 2] = np.nan
+        with pytest.raises(ValueError):
+            pkg.ess(xn, kind="tail")
+        with pytest.raises(ValueError):
+            pkg.ess(dev(xn), kind="tail")
+        assert np.array_equal(host(pkg.rhat(xn)), host(pkg.rhat(dev(xn))))   # (a NaN is ranked last: R-hat stays finite)
+        assert np.array_equal(host(pkg.ess(x, kind="tail")), host(pkg.ess(dev(x), kind="tail")))  # and nothing sticks to the context
+        # fewer parameters than two per block: the plain path
+        assert np.array_equal(host(pkg.rhat(x[:, :, :4])), host(pkg.rhat(dev(x[:, :, :4]))))
+
+
 def test_mcmcchains_storage_order(pkg):
     """(iterations, parameters, chains) input -- MCMCChains storage -- read IN PLACE through chain_stride /
     param_stride (no permuted copy), and through the device-side permutation helper: bit-equal to the dense call"""
