@@ -80,7 +80,8 @@ typedef struct mdt_ctx mdt_ctx; /* opaque: device, scratch, normal-score tables 
 typedef struct mdt_args {
     int64_t draws, chains, params; /* size(x, 1), size(x, 2), prod(size(x)[3:end]) */
     int32_t dtype;                 /* MDT_F64 / MDT_F32: eltype of x and of the outputs */
-    int32_t location;              /* MDT_HOST / MDT_DEVICE for x and all outputs */
+    int32_t location;              /* MDT_HOST / MDT_DEVICE for x and all outputs (MDT_HOST: staged by the library and the call is
+                                      synchronous; arrays of 128 MB and more travel in blocks of the params axis, copy under compute) */
     int32_t kind;                  /* MDT_KIND_* */
     int32_t outputs;               /* MDT_OUT_ESS | MDT_OUT_RHAT (mdt_ess_rhat only) */
     int32_t autocov;               /* MDT_AUTOCOV_* : keyword autocov_method */
