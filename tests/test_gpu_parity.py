@@ -415,6 +415,9 @@ def test_host_buffers_in_blocks(pkg, monkeypatch):
             pkg.ess(dev(xn), kind="tail")
         assert np.array_equal(host(pkg.rhat(xn)), host(pkg.rhat(dev(xn))))   # (a NaN is ranked last: R-hat stays finite)
         assert np.array_equal(host(pkg.ess(x, kind="tail")), host(pkg.ess(dev(x), kind="tail")))  # and nothing sticks to the context
+        # the children of a multi-GPU context stage their own blocks the same way
+        for a1, b1 in zip(pkg.bulk_tail(x, devices=[0]), pkg.bulk_tail(dev(x))):
+            assert np.array_equal(host(a1), host(b1))
         # fewer parameters than two per block: the plain path
         assert np.array_equal(host(pkg.rhat(x[:, :, :4])), host(pkg.rhat(dev(x[:, :, :4]))))
 
