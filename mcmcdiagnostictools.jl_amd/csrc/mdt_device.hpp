@@ -231,6 +231,33 @@ __device__ __forceinline__ MDT_GA P* uniptr_g(P* p) { return (MDT_GA P*)uni64((u
 // explicitly in the GLOBAL address space: across a call boundary a plain pointer is generic and
 // every access through it becomes a flat_load, which ties up both wait counters and serialises
 // against LDS traffic (measured: 352 flat loads + 2283 s_waitcnt in the rank phase).
+// Streams -- arrays a parameter passes through once per pass, far larger than the 4 MiB L2 of an XCD -- are marked
+// non-temporal so that they do not push the lines that ARE reused (the score table, the callee-saved register frames the
+// phase functions store and reload at every call: ~100 KB per workgroup and call) out of the L2.  Measured in round 3
+// on the streams of the tile-major path (x, the class-sorted chain image and its tags, the scores, the sorted copy):
+// loads alone -0.2 %, stores alone -2.1 %, both -2.3 ... -3.5 % on the headline by box, -2 % on config 5; the streams
+// of the histogram / partition / windowed passes (bit 2) re-read what they wrote soon enough to lose by it (config 3
+// +1.3 %).  MDT_STREAM_NT: build-time switch, bit 0 the loads, bit 1 the stores, bit 2 the second set (A/B timing).
+#ifndef MDT_STREAM_NT
+#define MDT_STREAM_NT 3
+#endif
+#if MDT_STREAM_NT & 1
+#define MDT_LD_STREAM(p) __builtin_nontemporal_load(p)
+#else
+#define MDT_LD_STREAM(p) (*(p))
+#endif
+#if MDT_STREAM_NT & 2
+#define MDT_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MDT_ST_STREAM(p, v) (*(p) = (v))
+#endif
+#if MDT_STREAM_NT & 4 /* the streams of the passes the tile-major path does not take (histogram, partition, windowed layout) */
+#define MDT_LD_STREAM2(p) __builtin_nontemporal_load(p)
+#define MDT_ST_STREAM2(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define MDT_LD_STREAM2(p) (*(p))
+#define MDT_ST_STREAM2(p, v) (*(p) = (v))
+#endif
 template <typename T>
 struct SrcPlain {      // x itself
     const MDT_GA T* xp;
@@ -242,6 +269,8 @@ struct SrcPlain {      // x itself
 #else
     __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)(xp + base)[i]; }
 #endif
+    // the one read of a pass that takes the slice once (tile-major pass)
+    __device__ __forceinline__ double at_stream(long long base, unsigned i) const { return (double)MDT_LD_STREAM((xp + base) + i); }
 };
 template <typename T>
 struct SrcFold {       // |x - median|, evaluated in T like the reference (src/utils.jl:155)
@@ -254,6 +283,9 @@ struct SrcFold {       // |x - median|, evaluated in T like the reference (src/u
     }
     __device__ __forceinline__ double at(long long base, unsigned i) const {
         const T d = (T)((xp + base)[i] - med);
+        return (double)(d < (T)0 ? -d : d);
+    }    __device__ __forceinline__ double at_stream(long long base, unsigned i) const {
+        const T d = (T)(MDT_LD_STREAM((xp + base) + i) - med);
         return (double)(d < (T)0 ? -d : d);
     }
 };
@@ -295,6 +327,14 @@ struct SerZ {          // series = normal scores, already in time order in the p
     __device__ __forceinline__ double operator()(int c, long long row) const { return z[(long long)c * D + row]; }
 };
 #define MDT_PHASE __device__ __attribute__((noinline))
+// The phases of the common path (two-level ranking, z-series, fold merge, pooled indicators).  As separate functions each
+// call saves and restores the 48 callee-saved VGPRs it touches: ~100 KB of scratch stores and as many loads per workgroup and
+// call.  MDT_INLINE_HOT builds them into the kernel body instead (A/B timing).
+#ifdef MDT_INLINE_HOT
+#define MDT_PHASE_HOT __device__ __forceinline__
+#else
+#define MDT_PHASE_HOT MDT_PHASE
+#endif
 // The dynamic LDS block reaches the phase functions as a plain pointer, but the compiler knows which symbol it is and
 // re-derives its address wherever it is used -- in a function that is not a kernel that is a LOAD from a table in
 // global memory (llvm.amdgcn.dynlds.offset.table), rematerialised inside hot loops (17 exposed L2 round trips in
