@@ -237,7 +237,7 @@ __device__ __forceinline__ MDT_GA P* uniptr_g(P* p) { return (MDT_GA P*)uni64((u
 // on the streams of the tile-major path (x, the class-sorted chain image and its tags, the scores, the sorted copy):
 // loads alone -0.2 %, stores alone -2.1 %, both -2.3 ... -3.5 % on the headline by box, -2 % on config 5; the streams
 // of the histogram / partition / windowed passes (bit 2) re-read what they wrote soon enough to lose by it (config 3
-// +1.3 %).  MDT_STREAM_NT: build-time switch, bit 0 the loads, bit 1 the stores, bit 2 the second set (A/B timing).
+// +1.3 %).  MDT_STREAM_NT: build-time switch, bit 0 the loads, bit 1 the stores, bits 2 / 3 the loads / stores of the second set (A/B timing).
 #ifndef MDT_STREAM_NT
 #define MDT_STREAM_NT 3
 #endif
@@ -251,11 +251,14 @@ __device__ __forceinline__ MDT_GA P* uniptr_g(P* p) { return (MDT_GA P*)uni64((u
 #else
 #define MDT_ST_STREAM(p, v) (*(p) = (v))
 #endif
-#if MDT_STREAM_NT & 4 /* the streams of the passes the tile-major path does not take (histogram, partition, windowed layout) */
+#if MDT_STREAM_NT & 4 /* the streams of the passes the tile-major path does not take (histogram, partition, windowed layout): loads */
 #define MDT_LD_STREAM2(p) __builtin_nontemporal_load(p)
-#define MDT_ST_STREAM2(p, v) __builtin_nontemporal_store((v), (p))
 #else
 #define MDT_LD_STREAM2(p) (*(p))
+#endif
+#if MDT_STREAM_NT & 8 /* ... and their stores */
+#define MDT_ST_STREAM2(p, v) __builtin_nontemporal_store((v), (p))
+#else
 #define MDT_ST_STREAM2(p, v) (*(p) = (v))
 #endif
 template <typename T>
