@@ -704,7 +704,13 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // (two 512-thread workgroups per CU: measured crossover at draws*chains ~ 12-16 K -- below it the
         // histogram + partition passes of the two-level variant cost more than re-streaming a slice that is
         // only one or two rounds long: 1000 x 4 x 100 000 takes 31.8 ms instead of 35.0, 200 x 4 x 500 000 132 instead of 161)
-        kp.rank_variant = rv ? atoi(rv) : ((small || tiny) ? (n <= 12288 ? 0 : 2) : (n >= 65535 ? 2 : 0));
+        // (round 3: since the folded ranking is a merge of the sorted copy the two-level variant leaves, it wins at EVERY slice
+        // size of the 512- and 256-thread geometries -- 1000 x 4 x 100 000 16.4 ms against 19.3, 2000 x 4 x 50 000 12.9 against
+        // 18.1, 1000 x 8 x 50 000 15.1 against 20.6, 50 x 4 x 400 000 38.3 against 39.1 -- and it is the default everywhere: one
+        // variant in every geometry also keeps R-hat the same BITS whichever geometry serves a slice (the merge and the general
+        // folded ranking take their moments around different shifts); the other two remain as its fallback (a coarse class
+        // larger than the chunk) and behind MDT_RANK_VARIANT)
+        kp.rank_variant = rv ? atoi(rv) : 2;
         // the round tables hold MAXROUNDS rounds of at most one LDS chunk each: beyond that the ranking cannot be served
         // (slices between half of that and that may still overflow on the device: status flag, NaN outputs)
         const long long chunk = tiny ? std::min(mdt_tiny::QCH, mdt_tiny::CH) : (small ? std::min(mdt_small::QCH, mdt_small::CH) : std::min(mdt_big::QCH, mdt_big::CH));
