@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of every kind / estimator on the BASELINE config-2 shape (10_000 x 4 x P Float64).  Usage: python tools/time_kinds.py [P]"""
+"""Timing of every kind / estimator on the BASELINE config-2 shape (10_000 x 4 x P Float64), or any other.
+Usage: python tools/time_kinds.py [P [DRAWS [CHAINS]]]"""
 import os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +10,9 @@ import __graft_entry__ as g
 from bench import synth
 pkg = g.load_package()
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
-x = synth(10000, 4, P, torch.device("cuda", 0), 1234).permute(2, 1, 0)
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+C = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+x = synth(D, C, P, torch.device("cuda", 0), 1234).permute(2, 1, 0)
 warnings.simplefilter("ignore")
 calls = [("ess_rhat basic", lambda: pkg.ess_rhat(x, kind="basic")), ("rhat basic", lambda: pkg.rhat(x, kind="basic")),
          ("ess_rhat bulk", lambda: pkg.ess_rhat(x, kind="bulk")), ("ess_rhat tail", lambda: pkg.ess_rhat(x, kind="tail")),
@@ -25,4 +28,4 @@ for name, f in calls:
         f()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 3
-    print(f"{name:20s} {dt*1e3:8.2f} ms  {P/dt:10.0f} param-series/s  {P*320000/dt/1e9:7.1f} GB/s of input")
+    print(f"{name:20s} {dt*1e3:8.2f} ms  {P/dt:10.0f} param-series/s  {P*D*C*8/dt/1e9:7.1f} GB/s of input")
