@@ -5,7 +5,9 @@ draws x chains x params Float64, with the HBM roofline fraction and a CPU baseli
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py
---gpus N ...` (one rank per GPU over RCCL).  A "step" is one fused bulk+tail pass
+--gpus N ...` (one rank per GPU over RCCL); started plainly as `python bench.py --gpus N` it launches that same command
+itself, as a child process, before anything touches a GPU, and exits with the child's code -- the line always reports
+`n_gpus` = `--gpus`, or the run fails.  A "step" is one fused bulk+tail pass
 (mdt_bulk_tail through the C-ABI) over one synthetic (draws, chains, params) array that is already
 resident in HBM.  Weak scaling: every GPU owns `--params` parameters (the params axis shards with
 no exchange); the only collective is the all-gather of the four small output
@@ -255,7 +257,72 @@ def other_configs(pkg, device, steps, warmup):
         },
         "status_flags": flags,
     }
+    del x, x_pcd
+    torch.cuda.empty_cache()
+    # ---- the headline request on two more shapes: config 1's per-parameter shape at scale (what a sampler emits: 1000 draws x
+    # 4 chains), and the shard BASELINE config 4 really puts on one GPU (1 000 000 params over 8 GPUs = 125 000 each, 40 GB)
+    for key, (D, C, P), label, nstep in (
+            ("config1_at_scale", (1_000, 4, 100_000), "config 1's slice shape (BASELINE.json configs[0]: 1000 draws x 4 chains) at 100000 params", steps),
+            ("config4_shard", (10_000, 4, 125_000), "one GPU's shard of BASELINE.json configs[3] (1000000 params over 8 GPUs), 40 GB resident", 3)):
+        x_pcd = synth(D, C, P, device, seed=1234, chunk=1000 if D >= 10_000 else 10_000)
+        x = x_pcd.permute(2, 1, 0)
+        outs = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
+        ms = timed_ms(lambda: pkg.bulk_tail(x, sync=False, out=outs), nstep, warmup)
+        flags = pkg.status()
+        pick = np.array([0, 5, P // 2 + 6, P - 1])
+        xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
+        want = c_oracle.bulk_tail(xs)
+        b_alg = D * C * 8 + 4 * 8
+        out[key] = {
+            "workload": f"ess_rhat bulk+tail, {D} draws x {C} chains x {P} params Float64: " + label,
+            "ms": ms, "param_series_per_s": P / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "achieved": P * b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_param": b_alg},
+            "parity_max_rel_err_vs_oracle": max_rel_err([o.cpu().numpy()[pick] for o in outs], want),
+            "parity_sample": f"{len(pick)} parameters against oracle/mdt_oracle.c", "status_flags": flags,
+        }
+        del x, x_pcd, outs
+        torch.cuda.empty_cache()
     return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
+    arguments>` as a CHILD process (never an exec: this process has not touched the GPU, and must not replace itself once
+    it has) and return its exit code.  Rank 0 of the child prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class DryRunEngine:
+    """MDT_BENCH_DRYRUN=1 (tests/test_bench_launch.py): the launch, sharding, gather, timing and reporting plumbing of this
+    file on CPU tensors over gloo, with the compute INJECTED -- every output is the global index of its parameter -- so that
+    `--gpus 2` can be shown to run two ranks and to report n_gpus 2 where there is no GPU.  Nothing here is a fallback of
+    the product: the line says "dry_run": true and carries no roofline, and bench.py refuses to run without a GPU otherwise."""
+
+    def __init__(self, p0):
+        self.p0 = p0
+
+    def bulk_tail(self, x, autocov_method=None, sync=False, out=None):
+        P = x.shape[2]
+        for o in out:
+            o.copy_(torch.arange(self.p0, self.p0 + P, dtype=o.dtype))
+        return out
+
+    def status(self):
+        return 0
+
+    class _M:
+        pass
+    AutocovMethod = FFTAutocovMethod = BDAAutocovMethod = _M
 
 
 def main():
@@ -277,30 +344,49 @@ def main():
     ap.add_argument("--autocov", choices=("direct", "fft", "bda"), default="direct",
                     help="autocov_method of the request (BASELINE config 3 forces fft)")
     args = ap.parse_args()
-    if args.streams > 1 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        raise SystemExit("--streams is a single-GPU experiment")
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: become one (a child process, started before any GPU call), so that the line printed
+        # is the N-GPU line the command asked for
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to "
+                         f"report a line whose n_gpus is not the one asked for")
+    if args.streams > 1 and world > 1:
+        raise SystemExit("--streams is a single-GPU experiment")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = os.environ.get("MDT_BENCH_DRYRUN") == "1"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if dry:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        if dry:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     else:
         dist = None
-
-    import __graft_entry__ as g
-    pkg = g.load_package()
+    dev_sync = (lambda: None) if dry else torch.cuda.synchronize
 
     D, C, P = args.draws, args.chains, args.params
-    x_pcd = synth(D, C, P, device, seed=1234, p0=rank * P)   # rank r owns global parameters [r P, (r + 1) P): generated on its GPU
+    if dry:
+        pkg = DryRunEngine(rank * P)
+        x_pcd = torch.from_numpy(synth(D, C, P, None, seed=1234, p0=rank * P))
+    else:
+        import __graft_entry__ as g
+        pkg = g.load_package()
+        x_pcd = synth(D, C, P, device, seed=1234, p0=rank * P)   # rank r owns global parameters [r P, (r + 1) P): generated on its GPU
     x = x_pcd.permute(2, 1, 0)                          # logical (draws, chains, params), zero-copy
     outs = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
     gathered = [torch.empty(world * P, dtype=torch.float64, device=device) for _ in range(4)] if world > 1 else None
@@ -323,25 +409,49 @@ def main():
             for o, gbuf in zip(outs, gathered):
                 dist.all_gather_into_tensor(gbuf, o)
 
+    # A diagnostic is normally called ONCE per array.  The first request of a process pays for the context (scratch
+    # allocation, the score table of the shape) and runs its tickets in parameter order; the next ones run them in the
+    # order of the costs the launch before measured ON THE SAME ARRAY.  Both are reported beside the
+    # steady state: the wall time of the very first call, of the second (context warm, first cost-ordered launch) and
+    # -- after the timed loop -- the steady state with the order switched off (ms_no_order).
+    cold = {}
+    if not dry and not streams and world == 1:
+        for name in ("first_call_ms", "second_call_ms"):
+            dev_sync()
+            tc = time.perf_counter()
+            step()
+            dev_sync()
+            cold[name] = (time.perf_counter() - tc) * 1e3
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
+    dev_sync()
+    if not dry:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()
+    if not dry:
+        ev0.record()
     for _ in range(args.steps):
         step()
-    ev1.record()
-    torch.cuda.synchronize()
+    if not dry:
+        ev1.record()
+    dev_sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dev_sync()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the stream the kernel runs on
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps if not dry else elapsed / args.steps * 1e3  # HIP events on the stream the kernel runs on
+    if world > 1:  # the gather did what it is there for: every rank holds every rank's block
+        for gbuf in gathered:
+            for r in range(world):
+                blk = gbuf[r * P:(r + 1) * P]
+                if dry:
+                    assert torch.equal(blk, torch.arange(r * P, (r + 1) * P, dtype=blk.dtype)), "gathered block mismatch"
+        if not dry:
+            assert all(torch.equal(gbuf[rank * P:(rank + 1) * P], o) for gbuf, o in zip(gathered, outs)), "gathered block mismatch"
     # the timed requests were asynchronous: what they could not raise is on the context (mdt_ctx_status)
     status_flags = pkg.status() if not streams else 0
     if status_flags:
@@ -380,7 +490,11 @@ def main():
                 "draws": D, "chains": C, "params_per_gpu": P, "autocov_method": type(method).__name__,
                 "split_chains": 2, "maxlag": 250, "tail_prob": 0.1, "sharding": f"params axis x{world}",
                 "streams": args.streams, "status_flags_after_timed_loop": status_flags,
+                "ticket_order": ("steady state: the timed launches hand out their tickets in the order of the per-parameter costs the launch "
+                                 "before measured on this same array (warm-up passes included; DESIGN.md 4.1d); a first call runs in parameter "
+                                 "order (first_call_ms), ms_no_order is the steady state with MDT_NO_ORDER=1"),
             },
+            **cold,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
@@ -410,8 +524,19 @@ def main():
             except Exception:
                 pass
 
+        if dry:
+            res["dry_run"] = True
+            del res["roofline"]
+    if rank == 0 and world == 1 and not dry and not streams:
+        # the steady state once more with the ticket order switched off (read per request): parameter order every launch
+        os.environ["MDT_NO_ORDER"] = "1"
+        try:
+            res["ms_no_order"] = timed_ms(step, args.steps, 1)
+        finally:
+            del os.environ["MDT_NO_ORDER"]
+
     # ---- CPU baseline (rank 0, N=1 only): the oracle ("port") on a bounded sample of the same data
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not dry and not args.no_cpu_baseline:
         from oracle import c_oracle
         c_oracle.build()
         got = [o.cpu().numpy() for o in outs]
@@ -478,7 +603,7 @@ def main():
                 del xa
         except Exception as e:  # the single-core figure above is the contractual one
             res["cpu_baseline_all_cores"] = {"error": str(e)}
-    if rank == 0 and world == 1 and not args.no_other_configs and (D, C, P) == (10000, 4, 10000) and not streams:
+    if rank == 0 and world == 1 and not dry and not args.no_other_configs and (D, C, P) == (10000, 4, 10000) and not streams:
         del x, x_pcd
         torch.cuda.empty_cache()
         res["other_configs"] = other_configs(pkg, device, steps=5, warmup=1)
