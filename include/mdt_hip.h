@@ -121,6 +121,11 @@ const char* mdt_last_error(const mdt_ctx* ctx);
  *   block is staged to its own GPU over PCIe (x or x_shards); (c) location == MDT_DEVICE with a single x: the array
  *   lives on ONE GPU (found from the pointer), the others fetch their block by a peer copy over xGMI -- a convenience
  *   for arrays that are already there, not a fast path.
+ *   Ordering against the producers of the input: (c) waits for args->stream, which must be a stream of the GPU that holds
+ *   x (NULL: that GPU's default stream); (a) has one producer per GPU and one stream slot, so the library synchronises
+ *   each device_ids[i] (hipDeviceSynchronize, on the worker of that GPU) before block i is read: work queued on any stream
+ *   of that GPU when the call is made is complete by then; work the caller queues later, from another thread, is not
+ *   waited for.  (b) reads host memory: the caller's.
  *   Outputs: [params] vectors in host memory, or on one of the devices (found from the pointer); every block's results
  *   reach them by one copy per output (in place when the block's GPU owns them).
  * Strided layouts (chain_stride / param_stride) are honoured per block.  Calls on a multi-GPU context are synchronous

@@ -3,7 +3,9 @@
 # NOT EXECUTED IN THIS REPOSITORY'S CI: Julia is not available in the build image.  It shows the
 # reference-side binding a maintainer would add: same function names, keyword arguments, array
 # convention and error types as MCMCDiagnosticTools.jl (src/MCMCDiagnosticTools.jl:17-25), one
-# `ccall` per request.  The tested host mirror is the Python package next to it.
+# `ccall` per request.  The tested host mirror is the Python package next to it.  Where Julia and a
+# GPU exist, `julia julia/test/runtests.jl` checks this file against the API behaviour the reference's
+# own suite demands -- and against MCMCDiagnosticTools.jl itself when that package is installed.
 #
 # Front door, as in the reference:
 #   * `Union{Missing,T}` eltypes: a parameter with any missing draw yields `missing`, the others are computed
@@ -64,26 +66,46 @@ _with_layout(a::MdtArgs, cs, ps, shards=C_NULL, pl=a.tail_p_lo, pu=a.tail_p_hi) 
     MdtArgs(a.draws, a.chains, a.params, a.dtype, a.location, a.kind, a.outputs, a.autocov, a.split_chains, a.relative,
             a.sync, a.maxlag, a.tail_prob, a.stream, cs, ps, shards, pl, pu)
 
+# An mdt_ctx is single-owner (include/mdt_hip.h: one call at a time per context): the handles are created under this lock
+# and every request holds it for the duration of its ccall (`_locked`), so tasks on several threads queue up instead of
+# entering the library together.  (The Python mirror keeps one lock per context; one lock for the module is enough here:
+# a request occupies the whole GPU anyway.)
+const _lock = ReentrantLock()
+_locked(f) = lock(f, _lock)
 const _ctx = Ref{Ptr{Cvoid}}(C_NULL)
 const _multi = Dict{Vector{Cint},Ptr{Cvoid}}()
 function ctx()
-    if _ctx[] == C_NULL
-        rc = ccall((:mdt_ctx_create, libmdt), Cint, (Ref{Ptr{Cvoid}}, Cint), _ctx, 0)
-        rc == 0 || error("mdt_ctx_create failed with status $rc (no MI355X visible?)")
+    _locked() do
+        if _ctx[] == C_NULL
+            rc = ccall((:mdt_ctx_create, libmdt), Cint, (Ref{Ptr{Cvoid}}, Cint), _ctx, 0)
+            rc == 0 || error("mdt_ctx_create failed with status $rc (no MI355X visible?)")
+        end
+        _ctx[]
     end
-    return _ctx[]
 end
 # one context over several GPUs of the node: contiguous blocks of the params axis, one per device (mdt_ctx_create_multi)
 function ctx(devices::AbstractVector{<:Integer})
     ids = collect(Cint, devices)
-    return get!(_multi, ids) do
-        h = Ref{Ptr{Cvoid}}(C_NULL)
-        rc = ccall((:mdt_ctx_create_multi, libmdt), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cint}, Cint), h, ids, length(ids))
-        rc == 0 || error("mdt_ctx_create_multi failed with status $rc")
-        h[]
+    _locked() do
+        get!(_multi, ids) do
+            h = Ref{Ptr{Cvoid}}(C_NULL)
+            rc = ccall((:mdt_ctx_create_multi, libmdt), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cint}, Cint), h, ids, length(ids))
+            rc == 0 || error("mdt_ctx_create_multi failed with status $rc")
+            h[]
+        end
     end
 end
 _ctx_for(devices) = devices === nothing ? ctx() : ctx(devices)
+# the context of a prepared request: pre-sharded input lives on several GPUs, and only the caller knows which
+function _ctx_for(devices, pr)
+    pr.shards === nothing || devices !== nothing ||
+        throw(ArgumentError("pre-sharded input (a Vector of device arrays) needs `devices = [id of the GPU holding block 1, ...]`"))
+    pr.shards === nothing || length(devices) == length(pr.shards) ||
+        throw(DimensionMismatch("$(length(pr.shards)) blocks but $(length(devices)) devices"))
+    return _ctx_for(devices)
+end
+# what every function here accepts: the reference's samples arrays, or the blocks of a pre-sharded one
+const Samples = Union{AbstractArray{<:Union{Missing,Real}},AbstractVector{<:AbstractArray{<:Real}}}
 
 """    status(; devices=nothing, clear=true) -> flags
 
@@ -92,7 +114,9 @@ NaN (the reference throws ArgumentError there), 4 FDist.  Only requests issued w
 function status(; devices=nothing, clear::Bool=true)
     f = Ref{Int32}(0)
     h = _ctx_for(devices)
-    _check(h, ccall((:mdt_ctx_status, libmdt), Cint, (Ptr{Cvoid}, Ref{Int32}, Int32), h, f, clear))
+    _locked() do
+        _check(h, ccall((:mdt_ctx_status, libmdt), Cint, (Ptr{Cvoid}, Ref{Int32}, Int32), h, f, clear))
+    end
     return f[]
 end
 
@@ -118,12 +142,14 @@ struct UnsupportedOnDevice <: Exception
 end
 Base.showerror(io::IO, e::UnsupportedOnDevice) = print(io, "unsupported on the device path: ", e.msg)
 
-# status -> exception; the message is read from the context the call was made on (single- or multi-GPU)
-function _check(h::Ptr{Cvoid}, rc::Cint)
+# status -> exception; the message is read from the context the call was made on (single- or multi-GPU).
+# `domval`: the offending value of a DomainError -- the only one on this path is `maxlag` (src/ess_rhat.jl:481,
+# `DomainError(maxlag, "maxlag must be >0.")`), so the callers that take a maxlag pass it.
+function _check(h::Ptr{Cvoid}, rc::Cint, domval=0)
     rc == 0 && return nothing
     msg = unsafe_string(ccall((:mdt_last_error, libmdt), Cstring, (Ptr{Cvoid},), h))
     rc == 1 && throw(ArgumentError(msg))
-    rc == 2 && throw(DomainError(0, msg))
+    rc == 2 && throw(DomainError(domval, msg))
     rc == 3 && throw(DimensionMismatch(msg))
     rc == 6 && throw(UnsupportedOnDevice(msg))
     error("libmdt_hip status $rc: $msg")
@@ -239,16 +265,18 @@ function _ess_rhat(x, kind::Symbol, outputs; kindcode::Int=_KIND[kind], relative
     a0 = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, kindcode, outputs, _code(autocov_method),
                                split_chains, relative, 1, maxlag, tp, C_NULL), pr.shards)
     a = kindcode == _EST[:quantile] ? a0 : _with_layout(a0, a0.chain_stride, a0.param_stride, a0.x_shards, pl, pu)
-    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices, pr)
     GC.@preserve x3 sh S R begin
-        _check(h, ccall((:mdt_ess_rhat, libmdt), Cint,
-                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                        h, a, _xptr(pr), _ptr(S), _ptr(R)))
+        _locked() do
+            _check(h, ccall((:mdt_ess_rhat, libmdt), Cint,
+                            (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                            h, a, _xptr(pr), _ptr(S), _ptr(R)), maxlag)
+        end
     end
     return S === nothing ? nothing : _out(x, pr, S), R === nothing ? nothing : _out(x, pr, R)
 end
 
-function ess(x::AbstractArray; kind=:bulk, kwargs...)
+function ess(x::Samples; kind=:bulk, kwargs...)
     kind === Statistics.mean && return first(_ess_rhat(x, :basic, 1; kwargs...))  # src/ess_rhat.jl:629
     # the other estimators with a proxy (src/ess_rhat.jl:630-659); the probability of a quantile travels in tail_prob
     kind === Statistics.median && return first(_ess_rhat(x, :basic, 1; kindcode=_EST[:median], kwargs...))
@@ -261,11 +289,11 @@ function ess(x::AbstractArray; kind=:bulk, kwargs...)
         throw(ArgumentError("the `kind` `$kind` is not supported by `ess`"))
     return first(_ess_rhat(x, kind, 1; kwargs...))
 end
-function rhat(x::AbstractArray; kind::Symbol=:rank, split_chains::Int=2, devices=nothing)
+function rhat(x::Samples; kind::Symbol=:rank, split_chains::Int=2, devices=nothing)
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat`"))
     return last(_ess_rhat(x, kind, 2; split_chains, devices))
 end
-function ess_rhat(x::AbstractArray; kind::Symbol=:rank, kwargs...)
+function ess_rhat(x::Samples; kind::Symbol=:rank, kwargs...)
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `ess_rhat`"))
     S, R = _ess_rhat(x, kind, 3; kwargs...)
     return (; ess=S, rhat=R)
@@ -283,7 +311,7 @@ end
 _nchains(x::AbstractArray) = size(x, 2)
 _nchains(x::AbstractVector{<:AbstractArray}) = size(first(x), 2)
 
-function rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind::Symbol=:rank,
+function rhat_nested(x::Samples, superchain_ids::AbstractVector; kind::Symbol=:rank,
                      split_chains::Int=2, devices=nothing)
     (x isa AbstractVector{<:AbstractArray} || ndims(x) >= 2) || throw(ArgumentError("`samples` must have at least 2 dimensions `(draws, chains[, parameters…])`"))
     inds = _superchain_inds(superchain_ids, _nchains(x))
@@ -294,11 +322,13 @@ function rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind::Sym
     D, C, P = size(pr)
     R = _newout(pr, P)
     a = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, _KIND[kind], 2, 0, split_chains, 0, 1, 250, 0.1, C_NULL), pr.shards)
-    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices, pr)
     GC.@preserve x3 sh R inds begin
-        _check(h, ccall((:mdt_rhat_nested, libmdt), Cint,
-                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}),
-                        h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(R)))
+        _locked() do
+            _check(h, ccall((:mdt_rhat_nested, libmdt), Cint,
+                            (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}),
+                            h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(R)))
+        end
     end
     return _out(x, pr, R)
 end
@@ -307,7 +337,7 @@ end
 
 `mcse(x)` (kind = mean) and `rhat_nested(x, superchain_ids; kind)` from ONE launch (mdt_mcse_nested): a parameter's
 slice is read from HBM once for both.  Bit-identical to the two calls; no counterpart in the reference."""
-function mcse_rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind::Symbol=:rank, split_chains::Int=2,
+function mcse_rhat_nested(x::Samples, superchain_ids::AbstractVector; kind::Symbol=:rank, split_chains::Int=2,
                           maxlag::Int=250, autocov_method::AbstractAutocovMethod=AutocovMethod(), devices=nothing)
     inds = _superchain_inds(superchain_ids, _nchains(x))
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `rhat_nested`"))
@@ -316,16 +346,18 @@ function mcse_rhat_nested(x::AbstractArray, superchain_ids::AbstractVector; kind
     D, C, P = size(pr)
     M, R = _newout(pr, P), _newout(pr, P)
     a = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, _KIND[kind], 3, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL), pr.shards)
-    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices, pr)
     GC.@preserve x3 sh M R inds begin
-        _check(h, ccall((:mdt_mcse_nested, libmdt), Cint,
-                        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
-                        h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(M), _ptr(R)))
+        _locked() do
+            _check(h, ccall((:mdt_mcse_nested, libmdt), Cint,
+                            (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Int32}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}),
+                            h, a, _xptr(pr), inds, size(inds, 1), size(inds, 2), _ptr(M), _ptr(R)), maxlag)
+        end
     end
     return _out(x, pr, M), _out(x, pr, R)
 end
 
-function mcse(x::AbstractArray; kind=Statistics.mean, autocov_method=AutocovMethod(),
+function mcse(x::Samples; kind=Statistics.mean, autocov_method=AutocovMethod(),
               split_chains::Int=2, maxlag::Int=250, devices=nothing)
     isq = kind === Statistics.median || kind isa Base.Fix2{typeof(Statistics.quantile),<:Real}
     kind === Statistics.mean || kind === Statistics.std || isq ||
@@ -337,16 +369,18 @@ function mcse(x::AbstractArray; kind=Statistics.mean, autocov_method=AutocovMeth
     out = _newout(pr, P)
     dt = T === Float32 ? 1 : 0
     a = _args_for(pr, MdtArgs(D, C, P, dt, pr.location, 0, 1, _code(autocov_method), split_chains, 0, 1, maxlag, 0.1, C_NULL), pr.shards)
-    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices)   # every kind runs on a multi-GPU context (each block on its own GPU)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices, pr)   # every kind runs on a multi-GPU context (each block on its own GPU)
     GC.@preserve x3 sh out begin
-        if isq  # kind code and probability travel in the args (src/mcse.jl:66-92)
-            aq = _args_for(pr, MdtArgs(D, C, P, dt, pr.location, kind === Statistics.median ? _EST[:median] : _EST[:quantile], 1,
-                                       _code(autocov_method), split_chains, 0, 1, maxlag, kind === Statistics.median ? 0.5 : Float64(T(kind.x)), C_NULL), pr.shards)
-            _check(h, ccall((:mdt_mcse_quantile, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, aq, _xptr(pr), _ptr(out)))
-        elseif kind === Statistics.mean
-            _check(h, ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)))
-        else
-            _check(h, ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)))
+        _locked() do
+            if isq  # kind code and probability travel in the args (src/mcse.jl:66-92)
+                aq = _args_for(pr, MdtArgs(D, C, P, dt, pr.location, kind === Statistics.median ? _EST[:median] : _EST[:quantile], 1,
+                                           _code(autocov_method), split_chains, 0, 1, maxlag, kind === Statistics.median ? 0.5 : Float64(T(kind.x)), C_NULL), pr.shards)
+                _check(h, ccall((:mdt_mcse_quantile, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, aq, _xptr(pr), _ptr(out)), maxlag)
+            elseif kind === Statistics.mean
+                _check(h, ccall((:mdt_mcse_mean, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)), maxlag)
+            else
+                _check(h, ccall((:mdt_mcse_std, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, _xptr(pr), _ptr(out)), maxlag)
+            end
         end
     end
     return _out(x, pr, out)
@@ -364,7 +398,11 @@ function bfmi(energy::AbstractMatrix{<:Real}; dims::Int=1)
     out = Vector{T}(undef, C)
     a = MdtArgs(D, C, 1, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
     h = ctx()
-    GC.@preserve e2 out _check(h, ccall((:mdt_bfmi, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, e2, out))
+    GC.@preserve e2 out begin
+        _locked() do
+            _check(h, ccall((:mdt_bfmi, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}), h, a, e2, out))
+        end
+    end
     return out
 end
 
@@ -379,8 +417,12 @@ function gelmandiag(chains::AbstractArray{<:Real,3}; alpha::Real=0.05)
     psrf, psrfci = Vector{Float64}(undef, P), Vector{Float64}(undef, P)
     a = MdtArgs(D, C, P, T === Float32 ? 1 : 0, 0, 0, 0, 0, 1, 0, 1, 250, 0.1, C_NULL)
     h = ctx()
-    GC.@preserve x3 psrf psrfci _check(h, ccall((:mdt_gelmandiag, libmdt), Cint,
-        (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}), h, a, x3, Float64(alpha), psrf, psrfci))
+    GC.@preserve x3 psrf psrfci begin
+        _locked() do
+            _check(h, ccall((:mdt_gelmandiag, libmdt), Cint,
+                            (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}), h, a, x3, Float64(alpha), psrf, psrfci))
+        end
+    end
     return (psrf=psrf, psrfci=psrfci)
 end
 

@@ -195,6 +195,11 @@ def _prepare_shards(shards):
     pr.P, pr.param_shape, pr.orig_shape, pr.scalar = P, (P,), (p0.D, p0.C, P), False
     pr.ptr, pr.shards, pr.missing = None, prs, None
     pr.xsh = (ctypes.c_void_p * len(prs))(*[q.ptr for q in prs])   # (kept alive with pr for the duration of the call)
+    # mdt_args has ONE stream slot: the producers of the other blocks run on streams of other GPUs.  The library
+    # synchronises every device before it reads its block (include/mdt_hip.h); the streams torch is using are waited for
+    # here as well, so the contract does not rest on one side only.
+    for q in prs:
+        torch.cuda.current_stream(q.buf.device).synchronize()
     return pr
 
 

@@ -839,7 +839,13 @@ int run_host_blocks(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& r
         if (rq.tpos_arr) rb.tpos_arr = rq.tpos_arr + 2 * lo;
         rb.keep_status = first ? rq.keep_status : 1;
         first = false;
-        if (int rc = run(ctx, &ab, (const char*)ctx->stage_x + off, rb)) return rc;
+        if (int rc = run(ctx, &ab, (const char*)ctx->stage_x + off, rb)) {
+            // (the checks of the request run inside run(): on a refusal the copy of this block from the caller's buffer is
+            // still in flight and earlier blocks are queued -- the caller may free x as soon as we return)
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
     }
     for (int i = 0; i < NOUT; ++i)
         if (outs_host[i]) HIP_TRY(hipMemcpyAsync(outs_host[i], (char*)ctx->stage_out + (size_t)i * P * ts, (size_t)P * ts, hipMemcpyDeviceToHost, st));
@@ -896,8 +902,14 @@ int for_shards(mdt_ctx* ctx, const mdt_args* a, const void* x, void* const* outs
                 out_dev = at.device;
                 break;
             }
-        // the producers of x have finished (the caller's stream belongs to the device that is current for the caller)
-        if (hipStreamSynchronize((hipStream_t)a->stream) != hipSuccess) return fail(ctx, MDT_ERUNTIME, "cannot synchronise the stream of x");
+        // The producers of the input have finished before any child reads it.  A single x: args->stream is a stream of the
+        // device that HOLDS x (a NULL stream is the default stream of whatever device is current, so that device is made
+        // current first).  Pre-sharded input has one producer per GPU and only one stream slot in the args: every worker
+        // synchronises its own device before it touches its block (below).
+        if (!a->x_shards) {
+            DeviceGuard gx(x_dev);
+            if (!gx.ok || hipStreamSynchronize((hipStream_t)a->stream) != hipSuccess) return fail(ctx, MDT_ERUNTIME, "cannot synchronise the stream of x");
+        }
     }
     auto job = [&](int i) -> int {
         mdt_ctx* child = ctx->children[i];
@@ -920,6 +932,8 @@ int for_shards(mdt_ctx* ctx, const mdt_args* a, const void* x, void* const* outs
                 hipPointerAttribute_t at;
                 if (hipPointerGetAttributes(&at, xs) != hipSuccess || at.device != child->device)
                     return fail(child, MDT_EARG, "x_shards[i] must live on device_ids[i] of the context");
+                // whatever stream of this GPU produced the block (non-blocking ones included) is done before it is read
+                HIP_TRY(hipDeviceSynchronize());
             }
         } else {
             xs = (const char*)x + (size_t)lo * (size_t)ps * ts;

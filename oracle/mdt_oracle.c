@@ -205,6 +205,8 @@ int mdt_oracle_bulk_tail_omp_f64(const mdt_oracle_args* a, const double* x, doub
     mallopt(M_MMAP_THRESHOLD, 32 << 20); /* (glibc's ceiling: HEAP_MAX_SIZE / 2; a block's largest temporary is a few MB) */
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
+    /* process-wide settings: put back to glibc's defaults after the parallel region (below), so that whatever the host
+     * process measures afterwards runs with the allocator it would have had without this call */
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
@@ -221,6 +223,10 @@ int mdt_oracle_bulk_tail_omp_f64(const mdt_oracle_args* a, const double* x, doub
             rc_all = rc;
         }
     }
+    mallopt(M_MMAP_THRESHOLD, 128 * 1024); /* glibc defaults (DEFAULT_MMAP_THRESHOLD, DEFAULT_TRIM_THRESHOLD, DEFAULT_TOP_PAD); */
+    mallopt(M_TRIM_THRESHOLD, 128 * 1024); /* setting them explicitly also switches the dynamic mmap threshold off, as the   */
+    mallopt(M_TOP_PAD, 128 * 1024);        /* first three calls already did                                                  */
+    malloc_trim(0);
     return rc_all;
 }
 

@@ -117,8 +117,12 @@ while time.time() - t0 < budget:
         wb = co.bulk_tail(x, autocov=m, split_chains=s, maxlag=ml)
         for rep in range(2 if ORDER else 1):
             eb, et, rb, rt = pkg.bulk_tail(xd, autocov_method=methods[m], split_chains=s, maxlag=ml)
-            for a, b in zip((eb, et, rb, rt), wb):
-                check(host(a), b, tol, what + f" fused (launch {rep + 1})", disc or short, short)
+            # Geyer's cut-off can tie exactly only where a series is discrete: every ESS of a discrete flavour, and ess_tail (an
+            # indicator series) on short chains.  R-hat never goes through Geyer's scan: no slack, ever.
+            check(host(eb), wb[0], tol, what + f" fused ess_bulk (launch {rep + 1})", disc, short)
+            check(host(et), wb[1], tol, what + f" fused ess_tail (launch {rep + 1})", disc or short, short)
+            assert_close(host(rb), wb[2], tol, what + f" fused rhat_bulk (launch {rep + 1})")
+            assert_close(host(rt), wb[3], tol, what + f" fused rhat_tail (launch {rep + 1})")
         for est, kind in (("median", np.median), ("mad", "mad")):
             got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             check(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), tol, what + " " + est, True, short)  # (an indicator series is discrete whatever x is)
