@@ -65,7 +65,7 @@ constexpr int GRID = TINY ? 256 : SMALL ? 512 : 2048; // uniform cells over [min
 constexpr int MAXROUNDS = 192;      // => n <= ~2.6M elements per parameter
 constexpr int TL = TINY ? 2048 : SMALL ? 4096 : 8192; // series tile (elements of one split chain resident in LDS)
 constexpr int MAXLAG_CAP = SMALL ? 255 : 1000;
-constexpr int HALO = SMALL ? 296 : 1040; // >= MAXLAG_CAP + 1 + 32 (one lag block past the last lag)
+constexpr int HALO = SMALL ? 352 : 1136; // >= MAXLAG_CAP + 16 + 64 + 16: the last lag tile's shifted operand behind a window's last 64-block
 constexpr int MAXM = 256;           // max number of split chains chains*split_chains
 constexpr int NLAGTAB = SMALL ? 256 : 1024;
 
@@ -610,7 +610,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const SrcPlain<T> VX{(const MDT_GA T*)xp};
         const SerX<T> YX{(const MDT_GA T*)xp, D};
         const SerZ YZ{(const MDT_GA double*)zb, D};
-        const bool zfast = (kp.niter + kp.maxlag + 40 <= SZ) && (kp.maxlag < SZ_EDGE);
+        // (a chain is processed in blocks of 64 values -- the last one zero-padded -- and the shifted operand of a lag tile
+        // reaches maxlag + 16 past it: 63 + 16 + 1 values of room behind niter + maxlag)
+        const bool zfast = (kp.niter + kp.maxlag + 80 <= SZ) && (kp.maxlag < SZ_EDGE);
 
         if (kp.niter == 0) { // mean of nothing: everything is NaN (src/ess_rhat.jl:391-406 with niter = 0)
             if (tid == 0) {

@@ -575,7 +575,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     else force_cfg = 0;
     // (measured: 1000 x 4 x 100 000 19.5 ms against 31.8 with two 512-thread workgroups per CU, 200 x 4 x 500 000 57 against
     // 132, 1000 x 12 x 30 000 28.4 against 36.1; no gain once a split chain no longer fits the z-series buffer)
-    const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 40 <= mdt_tiny::SZ && niter <= (long long)mdt_tiny::BITW * 64 &&
+    const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 80 <= mdt_tiny::SZ && niter <= (long long)mdt_tiny::BITW * 64 &&
                            (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
     const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU

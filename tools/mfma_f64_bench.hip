@@ -78,6 +78,69 @@ __global__ void coexec(double* out, long long* cyc, int iters, int mode) {
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = c1 - c0;
 }
 
+// ---- 2b. what ELSE shares the pipe: waves 4..7 run one of several instruction mixes beside the MFMA waves
+// kind 0: v_fma_f64, 1: 32-bit integer (v_add / v_xor / v_lshl), 2: v_cmp_lt_f64 + v_cndmask, 3: v_fma_f32, 4: ds_read_b64
+template <int KIND>
+__global__ void coexec2(double* out, long long* cyc, int iters, int mode) {
+    __shared__ double lds[4096];
+    const int w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = i * 1e-3;
+    __syncthreads();
+    double a = 1.0 + threadIdx.x * 1e-3, b = 1.0 - threadIdx.x * 1e-3;
+    double s = 0;
+    const long long c0 = clock64();
+    if (w < 4) {
+        if (mode != 2) {
+            d4 acc[4];
+            for (int i = 0; i < 4; ++i) acc[i] = d4{0, 0, 0, 0};
+            for (int it = 0; it < iters; ++it) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+            }
+            for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+        }
+    } else if (mode != 1) {
+        if (KIND == 1) {
+            unsigned v[16];
+            for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 2654435761u + i;
+            for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (v[i] + 0x9E3779B9u) ^ (v[i] << 3);
+            }
+            for (int i = 0; i < 16; ++i) s += v[i];
+        } else if (KIND == 2) {
+            double v[16];
+            for (int i = 0; i < 16; ++i) v[i] = a + i;
+            for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = (v[i] < b) ? a : v[(i + 1) & 15];
+                asm volatile("" : "+v"(b));
+            }
+            for (int i = 0; i < 16; ++i) s += v[i];
+        } else if (KIND == 3) {
+            float v[16];
+            float fa = (float)a, fb = (float)b;
+            for (int i = 0; i < 16; ++i) v[i] = 0.f;
+            for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) v[i] = fmaf(fa, fb, v[i]);
+                asm volatile("" : "+v"(fa));
+            }
+            for (int i = 0; i < 16; ++i) s += v[i];
+        } else if (KIND == 4) {
+            int idx = threadIdx.x & 63;
+            for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s += lds[(idx + 64 * i) & 4095];
+                asm volatile("" : "+v"(idx));
+            }
+        }
+    }
+    const long long c1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + w] = c1 - c0;
+}
+
 // ---- 3. the lag products of one chain of n values held in LDS, lags [0, 32)
 constexpr int NT = 512, NWAVE = 8, SZ = 6400;
 // vector form of rounds 1-3: waves = 4 lag groups of 8 x 2 time segments, two t per lane, 6 ds_read_b128 per 16 FMAs
@@ -199,6 +262,22 @@ int main() {
         double m0 = 0, m1 = 0; for (int i = 0; i < grid; ++i) for (int w = 0; w < 8; ++w) (w < 4 ? m0 : m1) += (double)hc[i * 8 + w];
         printf("coexec mode %d (%s): %.3f ms; mean ticks MFMA waves %.0f, VALU waves %.0f\n", mode, mode == 0 ? "both" : mode == 1 ? "MFMA waves only" : "VALU waves only", ms, m0 / grid / 4, m1 / grid / 4);
     }
+    auto co2 = [&](const char* name, auto kern) {
+        for (int mode : {1, 2, 0}) {
+            const int grid = 256;
+            float ms;
+            auto f = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), 0, 0, out, cyc, 5000, mode); };
+            f(); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0)); f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(hc.data(), cyc, (size_t)grid * 8 * 8, hipMemcpyDeviceToHost));
+            double m0 = 0, m1 = 0; for (int i = 0; i < grid; ++i) for (int w = 0; w < 8; ++w) (w < 4 ? m0 : m1) += (double)hc[i * 8 + w];
+            printf("coexec with %-28s mode %d (%s): %.3f ms; mean ticks MFMA waves %.0f, other waves %.0f\n", name, mode, mode == 0 ? "both" : mode == 1 ? "MFMA waves only" : "other waves only", ms, m0 / grid / 4, m1 / grid / 4);
+        }
+    };
+    co2("32-bit integer VALU", coexec2<1>);
+    co2("v_cmp_f64 + v_cndmask", coexec2<2>);
+    co2("v_fma_f32", coexec2<3>);
+    co2("ds_read_b64", coexec2<4>);
     // lag products
     const int n = 5000, nch = 512, reps = 200;
     std::vector<double> hz((size_t)nch * n);
