@@ -138,6 +138,7 @@ struct KP {
     int fold_merge;             // 1: rank |x - median| by merging the sorted slice when the ranking of x left one (fold_merge_phase); 0: always the general ranking (MDT_FOLD_MERGE=0: tests, A/B timing)
     int pa_on;                  // 1: tile-major partition where it applies (rank_phase_q, `pa`); 0: histogram + partition passes (MDT_PA=0: tests, A/B timing)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
+    int onechunk;               // 1: short slices take the one-chunk path (oc_rank_phase / oc_series_phase, mdt_short.inc) where it applies; 0: never (MDT_ONECHUNK=0: tests, A/B timing)
     long long maxlag;           // already min(maxlag, niter - 4)
     double rel_ess_max;         // log10(ntotal) evaluated in T on the host (src/ess_rhat.jl:514)
     double ntotal;              // niter * m
@@ -519,6 +520,8 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
 
 #include "mdt_nested.inc"
 
+#include "mdt_short.inc"
+
 // ------------------------------------------------------------------ the kernel
 template <typename T>
 __device__ __forceinline__ void store_out(void* p, long long i, double v) {
@@ -799,8 +802,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         // when an autocovariance follows, the windowed score layout of series_win_phase instead of a time-order scatter
         const bool long_chain = kp.winout && kp.niter + 41 > SZ && !fft_lds && kp.mode != 3 && kp.m + 1 <= 64 &&
                                 kp.maxlag + 40 + MAXROUNDS <= PT_CAP / 4;
-        int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order
-        if (need_rank_x) {
+        int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order; 5: the scores are in LDS (one-chunk path)
+        // short slices: the whole parameter in one LDS chunk (mdt_short.inc); a NaN in the slice sends it down the general path
+        bool oc = false;
+        if constexpr (OC_ON) {
+            oc = kp.onechunk && need_rank_x && kp.rank_variant == 2 && kp.mode == 0 && kp.est == 0 && n <= OC_MAX &&
+                 kp.rem == 0 && kp.m <= 8 && kp.niter >= 64 && zfast && !fft_lds && (kp.need_eb || kp.need_rb);
+            if (oc) {
+                oc = uni(oc_rank_phase<T>(kp, xp, n, smem, xs, bs, ntgt)) != 0;
+                if (oc) rk = 5;
+            }
+        }
+        if (need_rank_x && !oc) {
             if (kp.rank_variant == 2) {
                 rk = rank_phase_q(kp, VX, n, smem, zb, pbuf, bb, xs, bs, ntgt, kp.mode == 3,
                                   // order statistics only (no score is consumed): estimators, mcse quantile, tail-only requests
@@ -932,6 +945,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             // bits whichever autocovariance path follows
             if (many) { // time-order scores, one thread per split chain
                 so = many_phase(kp, YZ, xs, acov, smem, nested ? 1 : 0);
+            } else if (rk == 5) { // one-chunk path: every split chain is resident in LDS, one sweep over the pooled series
+                if constexpr (OC_ON) {
+                    bits_done = zq_ok && acov && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
+                    so = oc_series_phase(kp, acov, smem, bits_done ? gb : nullptr, zq[0], zq[1]);
+                    if (acov) so.ess = fft_const_chain_nan(so.ess);
+                }
             } else if (rk == 4) { // long chains: moments from the ranking, lag products from its windowed score layout
                 bits_done = zq_ok && 2LL * kp.m * ((kp.niter + 63) >> 6) <= kp.ibits_stride;
                 so = series_win_phase(kp, zb, pbuf, bb, smem, bits_done ? gb : nullptr, zq[0], zq[1]);

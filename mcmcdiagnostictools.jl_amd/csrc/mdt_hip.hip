@@ -577,7 +577,14 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // 132, 1000 x 12 x 30 000 28.4 against 36.1; no gain once a split chain no longer fits the z-series buffer)
     const bool tiny_fits = small_fits && n <= 12288 && niter + mdt_tiny::SZ_EDGE + 80 <= mdt_tiny::SZ && niter <= (long long)mdt_tiny::BITW * 64 &&
                            (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
-    const bool tiny = force_cfg == 0 ? tiny_fits : (force_cfg == 3 && tiny_fits);
+    // the one-chunk path (mdt_short.inc): a slice of at most 4000 values, at most eight split chains, no dropped rows, ranked and
+    // carried through the bulk series inside ONE chunk of the 512-thread geometry -- which then serves the request instead of
+    // the 256-thread one (measured, round 4: 1000 x 4 x 100 000 bulk+tail ... ms against 16.4).  MDT_ONECHUNK=0: never (tests, A/B timing)
+    const bool onechunk = !(getenv("MDT_ONECHUNK") && atoi(getenv("MDT_ONECHUNK")) == 0) && small_fits && rq.mode == 0 && !rq.basic &&
+                          rq.est == 0 && n <= (long long)mdt_small::OC_MAX && D % s == 0 && m <= 8 && niter >= 64 && !fft_lds &&
+                          niter + maxlag + 80 <= mdt_small::SZ && maxlag < mdt_small::SZ_EDGE && (rq.need_eb || rq.need_rb) &&
+                          !(getenv("MDT_RANK_VARIANT") && atoi(getenv("MDT_RANK_VARIANT")) != 2);
+    const bool tiny = force_cfg == 0 ? (tiny_fits && !onechunk) : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
 
     MDT_ON_DEVICE(ctx);
@@ -723,6 +730,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
     { const char* wo = getenv("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
     { const char* pe = getenv("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
+    kp.onechunk = onechunk ? 1 : 0;
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
     kp.out_mcse = outs_dev[5];

@@ -1392,3 +1392,73 @@ def test_tail_ess_beyond_131072_draws(pkg, monkeypatch):
             assert_close(a, b, RTOL64, f"{nm} 300000 draws unsplit {m}")
     for est, kind in (("median", np.median), ("mad", "mad"), ("quantile", pkg.Quantile(0.3))):
         assert_close(host(pkg.ess(yd, kind=kind, split_chains=1)), co.ess_estimator(y, est, prob=0.3, split_chains=1), RTOL64, f"ess {est} 300000 draws unsplit")
+
+
+def test_one_chunk_path_matches_the_general_path(pkg, methods, monkeypatch):
+    """Round 4: slices of at most 4000 values (1000 draws x 4 chains, what a sampler emits) are ranked and carried through
+    the bulk series inside ONE LDS chunk (csrc/mdt_short.inc): x read once, no histogram / partition passes, every split
+    chain resident at once, the lag products of all chains in one sweep over the pooled series.  MDT_ONECHUNK=0 sends the
+    same request down the general path: R-hat must be the same BITS (same fixed-point moments), the tied ranks the same
+    (ESS of ties and point masses), ESS within 1e-9 (other summation order of the lag products); a NaN in a slice falls
+    back by itself; the oracle agrees with both."""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(404)
+    x = ar1(0.6, 1000, 4, 14, rng)
+    x[:, :, 1] = rng.standard_normal((1000, 4))            # IID
+    x[:, :, 2] = np.round(x[:, :, 2], 1)                   # heavy ties
+    x[:, 2, 3] = 0.25                                      # a constant chain: W > 0, exact zeros in its deviations
+    x[:, :, 4] = 1.5                                       # a constant parameter: NaN, NaN
+    x[5, 1, 5] = np.inf; x[6, 1, 5] = -np.inf              # infinities rank first / last
+    x[7, 0, 6] = 0.0; x[8, 0, 6] = -0.0                    # signed zeros tie
+    x[:, :, 7] = np.exp(3.0 * x[:, :, 7])                  # heavy right tail: crowded bins
+    x[rng.random((1000, 4)) < 0.4, 8] = 0.25               # a point mass holding 40 % of the slice
+    x[:, :, 9] += 3.0 * rng.standard_normal((1, 4))        # chains that do not agree: every lag sweep
+    x[:, :, 10] = ar1(0.97, 1000, 4, 1, rng)[:, :, 0]      # slowly mixing: several sweeps
+    x[:, :, 11] = -x[:, :, 11]
+    x[1::2, :, 12] = -x[0:-1:2, :, 12]                     # antithetic: ESS at the cap
+    shapes = [("1000x4", x), ("996x4", x[:996]), ("500x2", x[:500, :2]), ("f32", x.astype(np.float32)), ("640x6", np.concatenate([x[:640], x[:640, :2]], axis=1))]
+
+    def run_all(xd, s):
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out += [("fused%d" % i, host(o)) for i, o in enumerate(pkg.bulk_tail(xd, split_chains=s))]
+            for kind in ("bulk", "tail", "rank"):
+                r = pkg.ess_rhat(xd, kind=kind, split_chains=s, autocov_method=methods["bda"] if kind == "bulk" else methods["direct"], maxlag=250 if kind != "rank" else 40)
+                out += [(kind + " ess", host(r.ess)), (kind + " rhat", host(r.rhat))]
+            out.append(("rhat only", host(pkg.rhat(xd, split_chains=s))))
+            out.append(("fft ess", host(pkg.ess(xd, kind="bulk", split_chains=s, autocov_method=methods["fft"]))))
+        return out
+
+    for what, xs in shapes:
+        for s in (2, 1):
+            if xs.shape[0] % s or xs.shape[1] * s > 8:
+                continue
+            xd = dev(xs)
+            monkeypatch.delenv("MDT_ONECHUNK", raising=False)
+            a = run_all(xd, s)
+            monkeypatch.setenv("MDT_ONECHUNK", "0")
+            b = run_all(xd, s)
+            monkeypatch.delenv("MDT_ONECHUNK")
+            for (ka, va), (kb, vb) in zip(a, b):
+                if "rhat" in ka or ka in ("fused2", "fused3"):
+                    assert np.array_equal(va, vb, equal_nan=True), (what, s, ka)
+                else:
+                    assert_close(va, vb, 1e-9 if xs.dtype == np.float64 else 2e-6, f"{what} s={s} {ka}")
+            if xs.dtype == np.float64:
+                want = co.bulk_tail(xs, split_chains=s)
+                for i in range(4):
+                    assert_close(a[i][1], want[i], RTOL64, f"{what} s={s} oracle {i}")
+    # a NaN anywhere in a slice: the general path serves that parameter (and the others stay on the one-chunk path)
+    xn = x[:, :, :4].copy()
+    xn[17, 2, 1] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = [host(pkg.rhat(dev(xn), kind=k)) for k in ("bulk", "tail", "rank")]
+        monkeypatch.setenv("MDT_ONECHUNK", "0")
+        b = [host(pkg.rhat(dev(xn), kind=k)) for k in ("bulk", "tail", "rank")]
+        monkeypatch.delenv("MDT_ONECHUNK")
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v, equal_nan=True)
+    assert pkg.status() in (0, 2)

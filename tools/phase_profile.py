@@ -20,16 +20,37 @@ import torch  # noqa: E402
 import __graft_entry__ as g  # noqa: E402
 from bench import synth  # noqa: E402
 
-NAMES = {0: "load x -> registers", 1: "rank x (tail)", 2: "series bulk (moments+autocov+Geyer)", 3: "rank |x-med| (tail)",
-         4: "series tail (moments)", 5: "indicators (tail ESS)", 6: "outputs",
-         8: "  rank: sample+sort+splitters", 9: "  rank: histogram", 10: "  rank: scan+rounds", 11: "  rank: place",
-         12: "  rank: count", 13: "  zseries: loads+stores", 14: "  zseries: barrier", 15: "  zseries: products+reductions",
-         7: "  zseries: finalize"}
+# What every slot covers -- a stamp charges the time since the previous stamp of thread 0 to its slot (MDT_PROF_MARK in
+# csrc/mdt_device.hpp), so a slot is "whatever ran between two stamps", named here by the code between them.
+# Slots 1-6 are stamped by the kernel body AFTER a phase returned: with the sub-slots below active they only hold the
+# tail of the phase behind its last inner stamp.
+NAMES = {1: "ranking of x: after its last round (shift K_j of every chain, return)",
+         2: "bulk series: after its last sweep (outputs of the phase, constant-chain check)",
+         3: "folded ranking |x - median| (fold merge, or the general ranking where no sorted copy exists)",
+         4: "R-hat of the folded scores (combine)",
+         5: "tail-ESS indicators (popcount autocovariance, Geyer)",
+         6: "outputs",
+         8: "  ranking: sample sort, splitters, grid LUT",
+         9: "  ranking: first pass over x (tile-major partition of every chain; two-pass form: class histogram + tags)",
+         10: "  ranking: class totals -> rounds",
+         11: "  ranking: partition pass (two-pass form only) + per round: load, local bins, placement + score output",
+         12: "  ranking: per round: count inside bins, sorted copy, score lookup"}
+# z-series with a split chain resident in LDS (series_z_phase: the headline, configs 1, 4, 5)
+NAMES_Z = {13: "  series: waiting for a chain's loads + scatter to time order in LDS + exact moments",
+           14: "  series: barrier per chain",
+           7: "  series: next chain's loads issued + centring terms of the chain (wave 0)",
+           15: "  series: lag products (+ indicator ballots, first sweep)"}
+# long chains (series_win_phase: config 3): a window = a partition tile of a chain, gathered run by run
+NAMES_W = {7: "  series (windows): barrier behind the products of the window before (waves waiting for the slowest)",
+           13: "  series (windows): waiting for the window's loads + placing it in LDS",
+           14: "  series (windows): run tables + issuing the next window's loads",
+           15: "  series (windows): lag products (+ indicator ballots, first sweep)"}
 
 
-NAMES_Q = {13: "  rank: partition pass", 14: "  rank: round load + local histogram", 15: "  rank: round prefix",
-           7: "  rank: round output (scores / tags)", 11: "  rank: round placement", 12: "  rank: round scores: table lookup, back to partition order",
-           0: "  rank: round count loop (+ sorted value store)", 6: "  rank: round sorted tags (+ outputs)"}
+NAMES_Q = {13: "  ranking: partition pass (two-pass form only)", 14: "  ranking: round load + local histogram", 15: "  ranking: round prefix",
+           7: "  ranking: round output (scores / moments)", 11: "  ranking: round placement",
+           12: "  ranking: round scores: table lookup, back to partition order",
+           0: "  ranking: round count loop (+ sorted value store)", 6: "  ranking: round sorted tags (+ outputs of the kernel)"}
 
 
 NAMES_F = {13: "  fold merge: tile boundaries", 14: "  fold merge: staging (loads, fold, LDS stores)", 15: "  fold merge: diagonal search + merge",
@@ -72,9 +93,14 @@ def main():
     ms = ev0.elapsed_time(ev1) / a.reps
     top = sum(buf[i] for i in range(16))  # every stamp advances the shared clock: the slots partition the time
     print(f"{a.draws}x{a.chains}x{a.params}: {ms:.3f} ms per call, {a.params / ms * 1e3:.0f} param-series/s")
-    names = {**NAMES, **NAMES_Q} if a.q else ({**NAMES, **NAMES_F} if a.f else NAMES)
+    # which series phase serves the shape: a split chain (draws / 2) + its halo fits the LDS buffer of 6400 values, or windows
+    series = NAMES_W if a.draws // 2 + 41 > 6400 else NAMES_Z
+    names = {**NAMES, **NAMES_Q} if a.q else ({**NAMES, **NAMES_F} if a.f else {**NAMES, **series})
     for i in sorted(names):
-        print(f"{names[i]:42s} {100.0 * buf[i] / top:6.2f} %")
+        print(f"{100.0 * buf[i] / top:6.2f} %  {names[i]}")
+    other = sum(buf[i] for i in range(16) if i not in names)
+    if other:
+        print(f"{100.0 * other / top:6.2f} %  (slots without a stamp in this build)")
 
 
 if __name__ == "__main__":
