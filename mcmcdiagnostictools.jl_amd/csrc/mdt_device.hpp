@@ -262,8 +262,25 @@ __device__ __forceinline__ MDT_GA P* uniptr_g(P* p) { return (MDT_GA P*)uni64((u
 #else
 #define MDT_ST_STREAM2(p, v) (*(p) = (v))
 #endif
+// Keys in the per-workgroup scratch (the partitioned copy, the sorted copy of the fold merge): stored in the type of the
+// data -- Float32 slices as 4-byte keys (exact: every key IS a Float32), everything else as doubles (round 4: the scratch
+// traffic of the config-5 shard, 10 000 x 16 Float32, was that of a Float64 array)
+template <typename T>
+using xs_of = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
+// The normal-score table in the same spirit: the scores of Float32 data are Float32 values (src/utils.jl:182 evaluates
+// norminvcdf in the eltype), so their table holds 4-byte entries -- half the table traffic, and 1.9 MB instead of 3.8 at
+// config 5's slice size, against 4 MB of L2 per XCD.
+template <typename T>
+struct ZTab {
+    const MDT_GA xs_of<T>* p;
+    __device__ __forceinline__ double operator[](unsigned long long i) const { return (double)p[i]; }
+};
+template <typename T, class KPT>
+__device__ __forceinline__ ZTab<T> ztab_of(const KPT& kp) { return ZTab<T>{(const MDT_GA xs_of<T>*)uni64((unsigned long long)kp.ztab)}; }
 template <typename T>
 struct SrcPlain {      // x itself
+    typedef xs_of<T> xs_t;
+    typedef T val_t;
     const MDT_GA T* xp;
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); }
     __device__ __forceinline__ double operator()(long long e) const { return (double)xp[e]; }
@@ -278,6 +295,8 @@ struct SrcPlain {      // x itself
 };
 template <typename T>
 struct SrcFold {       // |x - median|, evaluated in T like the reference (src/utils.jl:155)
+    typedef xs_of<T> xs_t;
+    typedef T val_t;
     const MDT_GA T* xp;
     T med;
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); med = uni(med); }
@@ -507,7 +526,8 @@ __global__ void ztab_kernel(double* tab, long long n, int f32) {
         z = norminv_acc(q);
         if (f32) z = (double)(float)z;
     }
-    tab[i0] = z;
+    if (f32) ((float*)tab)[i0] = (float)z; // (Float32 data: a table of Float32 scores, see ZTab)
+    else tab[i0] = z;
 }
 
 #include "mdt_rank.inc"
@@ -546,7 +566,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
     double* xs = kp.xsbuf + (long long)blockIdx.x * kp.n_pad;
     unsigned short* bs = kp.bsbuf + (long long)blockIdx.x * kp.n_pad;
     const bool pos16 = n < 65535;
-    const double* __restrict__ ztab = kp.ztab;
+    const ZTab<T> ztab = ztab_of<T>(kp);
     const double nan = __builtin_nan("");
     if (kp.prof && tid == 0) *(long long*)(smem + OFF_PROFT) = clock64();
 
