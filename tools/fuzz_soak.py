@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Soak test (needs a GPU; not part of the pytest suite): random shapes up to ~150 000 values per slice, splits,
 kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many|order]
-(long: chains of 50 000 - 131 072 draws; many: 100 - 1500 chains, more split chains than the LDS moment tables hold;
+(long: chains of 50 000 - 131 072 draws, maxlag up to 1000; many: 100 - 1500 chains, more split chains than the LDS moment tables hold;
 order: 600 - 4000 short parameters per request, each request issued twice -- the second launch hands its tickets out by
 the costs the first one measured.  Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
 import os, sys, time, warnings
@@ -75,6 +75,10 @@ while time.time() - t0 < budget:
         os.environ["MDT_PA"] = "2"
     else:
         os.environ.pop("MDT_PA", None)
+    if it % 3 == 0:  # the one-chunk path wherever it can run (by default only slices of 2561 ... 4000 values take it)
+        os.environ["MDT_ONECHUNK"] = "2"
+    else:
+        os.environ.pop("MDT_ONECHUNK", None)
     fl = ("normal", "ar", "ties", "skew", "offset", "mass")[it % 6]
     if fl == "normal":
         x = rng.standard_normal((D, C, P))
@@ -93,7 +97,7 @@ while time.time() - t0 < budget:
     if f32:
         x = x.astype(np.float32)
     tol = 5e-6 if f32 else 1e-8
-    ml = int(rng.choice([1, 7, 100, 250]))
+    ml = int(rng.choice([1, 7, 100, 250, 600, 1000] if LONG else [1, 7, 100, 250]))  # (long chains: the lag tiles of the windowed series up to the cap)
     m = ("direct", "fft", "bda")[it % 3]
     cfg = ("", "", "small", "big", "tiny")[it % 5]
     if cfg:
