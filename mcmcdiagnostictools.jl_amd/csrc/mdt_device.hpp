@@ -829,7 +829,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             oc = kp.onechunk && need_rank_x && kp.rank_variant == 2 && kp.mode == 0 && kp.est == 0 && n <= OC_MAX &&
                  kp.rem == 0 && kp.m <= 8 && kp.niter >= 64 && zfast && !fft_lds && (kp.need_eb || kp.need_rb);
             if (oc) {
-                oc = uni(oc_rank_phase<T>(kp, xp, n, smem, xs, bs, ntgt)) != 0;
+                oc = uni(oc_rank_phase<T>(kp, xp, n, smem, ntgt)) != 0;
                 if (oc) rk = 5;
             }
         }
@@ -958,6 +958,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
 
         double eb = nan, rb = nan, et = nan, rt = nan;
+        bool rt_done = false;
+        if constexpr (OC_ON) {
+            // one-chunk path: the folded ranking comes FIRST, as a merge of the sorted copy that still sits in LDS (the bulk
+            // series then takes its place); when it cannot serve the slice (ties in bulk) the general folded ranking runs
+            // after the bulk series, as everywhere else
+            if (rk == 5 && kp.need_rt && (medT - medT == (T)0)) {
+                if (uni(oc_fold_phase<T>(kp, medT, n, smem, bb)) == 3) {
+                    if (tid == 0) series_combine(kp, smem, 0, 1, false);
+                    __syncthreads();
+                    rt = scal[2]; // (the next write to it lies behind the barriers of the series phase)
+                    rt_done = true;
+                }
+                MDT_PROF_MARK(PH_RANKF);
+            }
+        }
         if (kp.need_eb || kp.need_rb) {
             const bool acov = kp.need_eb && kp.ess_ok;
             SeriesOut so;
@@ -1002,7 +1017,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         }
         MDT_PROF_MARK(PH_SERB);
         MDT_STOP(2)
-        if (kp.need_rt) {
+        if (kp.need_rt && !rt_done) {
             rk = 0;
             if (sorted_ok && (medT - medT == (T)0)) rk = fold_merge_phase<T>(kp, medT, n, smem, xs, bs, bb);
             if (rk != 3) rank_folded(0, kp.mode != 3 ? 2 : 0);

@@ -579,10 +579,10 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
                            (!fft_lds || niter + maxlag + 1 <= mdt_tiny::FFT_MAXN);
     // the one-chunk path (mdt_short.inc): a slice of at most 4000 values, at most eight split chains, no dropped rows, ranked and
     // carried through the bulk series inside ONE chunk of the 512-thread geometry -- which then serves the request instead of
-    // the 256-thread one.  Measured in round 4 (bulk+tail, ms, one-chunk / 256-thread general path): 1000 x 4 x 100 000 16.42 /
-    // 16.86, 2000 x 2 x 50 000 8.03 / 8.09, 500 x 4 x 100 000 14.82 / 12.85: it pays where the 256-thread geometry needs two
-    // rounds (more than 2560 values) and loses below, where four small workgroups per CU hide the per-parameter latency
-    // chains better than two large ones.  MDT_ONECHUNK=0: never, 2: wherever it can run (tests, A/B timing)
+    // the 256-thread one.  Measured in round 4 (bulk+tail, ms, one-chunk / 256-thread general path): 1000 x 4 x 100 000 14.80 /
+    // 16.88, 2000 x 2 x 50 000 7.17 / 8.04, 600 x 4 x 100 000 13.72 / 13.76, 500 x 4 x 100 000 13.36 / 12.77: it pays where the
+    // 256-thread geometry needs two rounds (more than 2560 values) and loses below, where four small workgroups per CU hide the
+    // per-parameter latency chains better than two large ones.  MDT_ONECHUNK=0: never, 2: wherever it can run (tests, A/B timing)
     const int oc_env = getenv("MDT_ONECHUNK") ? atoi(getenv("MDT_ONECHUNK")) : 1;
     const bool onechunk = oc_env != 0 && small_fits && rq.mode == 0 && !rq.basic &&
                           rq.est == 0 && n <= (long long)mdt_small::OC_MAX && (oc_env == 2 || n > (long long)mdt_tiny::QCH) && D % s == 0 && m <= 8 &&

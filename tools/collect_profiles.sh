@@ -2,7 +2,7 @@
 # Collect the round's evidence on the GPU box: bench line (headline + other_configs), rocprofv3 kernel stats of the same
 # command, calibrated PMC traffic for the three measured workloads, per-phase cycle tables.
 # usage (inside gpurun): bash tools/collect_profiles.sh <tag>      then, back home: python tools/summarize_profiles.py <tag>
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r03}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r04}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 MDT_PROF=1 python tools/phase_profile.py --params 10000 > $O/phase_cfg2.txt 2>/dev/null
@@ -14,6 +14,9 @@ for v in q:rank f:fold; do
   MDT_LIB=$R/tools/exp/libprof${v%%:*}.so MDT_PROF=1 python tools/phase_profile.py --${v%%:*} --draws 100000 --chains 8 --params 1000 > $O/phase_cfg3_${v##*:}.txt 2>/dev/null
   MDT_LIB=$R/tools/exp/libprof${v%%:*}.so MDT_PROF=1 python tools/phase_profile.py --${v%%:*} --cfg5 --params 12500 > $O/phase_cfg5_${v##*:}.txt 2>/dev/null
 done
+# config 1's slice shape at scale (the one-chunk path of round 4), default and with the sub-slots of the fold merge
+MDT_PROF=1 python tools/phase_profile.py --params 100000 --draws 1000 --chains 4 > $O/phase_cfg1.txt 2>/dev/null
+[ -f tools/exp/libproff.so ] && MDT_LIB=$R/tools/exp/libproff.so MDT_PROF=1 python tools/phase_profile.py --f --params 100000 --draws 1000 --chains 4 > $O/phase_cfg1_fold.txt 2>/dev/null
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
 bash tools/pmc_sq.sh > $O/sq_counters.txt 2>/dev/null
@@ -26,6 +29,12 @@ for cfg in cfg2:10000 cfg3:1000 cfg5:12500; do
 done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_cal -- $R/tools/scatter_bench > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_cal -- $R/tools/scatter_bench > /dev/null 2>&1
+# per-phase counters (SQ, LDS conflicts, MFMA, FETCH / WRITE) of the three measured workloads, by MDT_STOP_AFTER difference
+for cfg in cfg2:10000 cfg3:1000 cfg5:12500; do
+  bash $R/tools/pmc_phases.sh ${cfg%%:*} ${cfg##*:} > $O/pmc_phases_${cfg%%:*}.txt 2>&1
+done
+$R/tools/mfma_f64_bench > $O/mfma_microbench.txt 2>&1
+cd $R
 cat $O/bench.json
 # keep the merge-back small (64 MiB): of every CSV only the rows of this library's kernels (the synthetic-input generator
 # launches thousands of torch kernels), nothing else of rocprofv3's output

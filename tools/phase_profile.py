@@ -53,8 +53,10 @@ NAMES_Q = {13: "  ranking: partition pass (two-pass form only)", 14: "  ranking:
            0: "  ranking: round count loop (+ sorted value store)", 6: "  ranking: round sorted tags (+ outputs of the kernel)"}
 
 
-NAMES_F = {13: "  fold merge: tile boundaries", 14: "  fold merge: staging (loads, fold, LDS stores)", 15: "  fold merge: diagonal search + merge",
-           7: "  fold merge: moment atomics"}
+NAMES_F = {13: "  fold merge: tile boundaries (one-chunk path: median place, tables, score loads)",
+           14: "  fold merge: staging: loads, fold, LDS stores (one-chunk path: diagonal search)",
+           15: "  fold merge: diagonal search + merge (one-chunk path: merge + moment atomics)",
+           7: "  fold merge: moment atomics (one-chunk path: members with equals, sums -> moments)"}
 
 
 def main():

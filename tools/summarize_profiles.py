@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
 import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 shutil.copy(os.path.join(src, "bench.json"), f"profiles/{tag}_bench.json")
@@ -36,6 +36,7 @@ if tr:
                 t = d[w0:w0 + under["steps"]]
                 fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)}): mean {sum(t) / len(t):.3f} ms\n")
 for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "phase_cfg3_rank", "phase_cfg3_fold", "phase_cfg5_rank", "phase_cfg5_fold",
+             "phase_cfg1", "phase_cfg1_fold", "pmc_phases_cfg2", "pmc_phases_cfg3", "pmc_phases_cfg5", "mfma_microbench",
              "strided", "kinds", "sq_counters"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p) and os.path.getsize(p):
