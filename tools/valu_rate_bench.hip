@@ -47,6 +47,12 @@ KERNEL(k_cndmask_s, unsigned a[N]; unsigned b = threadIdx.x; unsigned long long 
        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(msk)), a[i])
 KERNEL(k_cmp_cnd, unsigned a[N]; unsigned b = threadIdx.x; for (int i = 0; i < N; ++i) a[i] = i * 3 + threadIdx.x,
        asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"), a[i])
+KERNEL(k_cmp_cnd2, unsigned a[N]; unsigned a2[N]; unsigned b = threadIdx.x; for (int i = 0; i < N; ++i) { a[i] = i * 3 + threadIdx.x; a2[i] = i; },
+       asm volatile("v_cmp_lt_u32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc" : "+v"(a[i]), "+v"(a2[i]) : "v"(b) : "vcc"), a[i] + a2[i])
+KERNEL(k_cmp_cnd4, unsigned a[N]; unsigned a2[N]; unsigned b = threadIdx.x; for (int i = 0; i < N; ++i) { a[i] = i * 3 + threadIdx.x; a2[i] = i; },
+       asm volatile("v_cmp_lt_u32 vcc, %0, %2\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_cndmask_b32 %1, %1, %2, vcc" : "+v"(a[i]), "+v"(a2[i]) : "v"(b) : "vcc"), a[i] + a2[i])
+KERNEL(k_cmps_cnd2, unsigned a[N]; unsigned a2[N]; unsigned b = threadIdx.x; unsigned long long m[N]; for (int i = 0; i < N; ++i) { a[i] = i * 3 + threadIdx.x; a2[i] = i; m[i] = 0; },
+       asm volatile("v_cmp_lt_u32 %3, %0, %2\n\tv_cndmask_b32_e64 %0, %0, %2, %3\n\tv_cndmask_b32_e64 %1, %1, %2, %3" : "+v"(a[i]), "+v"(a2[i]) : "v"(b), "s"(m[i])), a[i] + a2[i])
 KERNEL(k_max_u32, unsigned a[N]; unsigned b = threadIdx.x; for (int i = 0; i < N; ++i) a[i] = i * 3 + threadIdx.x,
        asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b)), a[i])
 KERNEL(k_bfi, unsigned a[N]; unsigned b = threadIdx.x; unsigned c = 0xFF00FF00u; for (int i = 0; i < N; ++i) a[i] = i * 3 + threadIdx.x,
@@ -72,14 +78,14 @@ int main() {
     struct { const char* name; void (*k)(double*, long long*, int); } ks[] = {
         {"v_cmp_lt_f64", k_cmp_f64}, {"v_cmp_lt_f32", k_cmp_f32}, {"v_cmp_lt_u32", k_cmp_u32}, {"v_cmp_lt_u64", k_cmp_u64},
         {"v_add_f64", k_add_f64}, {"v_min_f64", k_min_f64}, {"v_mul_f64", k_mul_f64}, {"v_add_f32", k_add_f32}, {"v_add_u32", k_add_u32},
-        {"v_cndmask_b32", k_cndmask}, {"v_cndmask s[]", k_cndmask_s}, {"cmp+cndmask pair", k_cmp_cnd}, {"v_max_u32", k_max_u32}, {"v_bfi_b32", k_bfi},
+        {"v_cndmask_b32", k_cndmask}, {"v_cndmask s[]", k_cndmask_s}, {"cmp+cndmask pair", k_cmp_cnd}, {"cmp+2 cndmask vcc", k_cmp_cnd2}, {"cmp+4 cndmask vcc", k_cmp_cnd4}, {"cmp+2 cndmask s[]", k_cmps_cnd2}, {"v_max_u32", k_max_u32}, {"v_bfi_b32", k_bfi},
         {"v_fma_f64", k_fma_f64}, {"v_pk_fma_f32", k_pk_fma_f32}, {"v_lshl_add_u32", k_lshl_add}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_mov_b32_dpp", k_mov_dpp}};
     // (clock64 of wave 0 is not a throughput: with several waves per SIMD the arbiter favours the oldest wave, which then finishes
     // its loop at the one-wave rate while the launch takes proportionally longer -- throughput is taken from the wall clock)
     printf("%-16s %s\n", "instruction", "wave-instructions per ns and SIMD (wall clock) at 1 / 2 / 4 waves per SIMD; in brackets clock64 ticks per instruction of wave 0");
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& k : ks) {
-        printf("%-16s", k.name);
+        printf("%-18s", k.name);
         for (int bs : {256, 512, 1024}) {
             hipLaunchKernelGGL(k.k, dim3(256), dim3(bs), 0, 0, out, cyc, iters);
             CK(hipDeviceSynchronize());
