@@ -236,7 +236,7 @@ Random.seed!(20261004)
         Rb, Rt = ROC.rhat_nested(x, [1, 1, 2, 2]; kind=:bulk), ROC.rhat_nested(x, [1, 1, 2, 2]; kind=:tail)
         @test ROC.rhat_nested(x, [1, 1, 2, 2]; kind=:rank) == max.(Rb, Rt)
         many = randn(10, 2048, 4)                       # the reference's many-short-chains case
-        @test all(r -> isapprox(r, 1; atol=0.05), ROC.rhat_nested(many, repeat(1:8; inner=256); kind=:basic) .- 0 .* 1)
+        @test all(r -> isapprox(r, 1; atol=0.05), ROC.rhat_nested(many, repeat(1:8; inner=256); kind=:basic))
     end
 
     @testset "mcse (test/mcse.jl:9-101)" begin
