@@ -25,14 +25,15 @@ if tr:
         under = None
     with open(f"profiles/{tag}_kernel_dispatches.txt", "w") as fo:
         sw = f"--steps {under['steps']} --warmup {under['warmup']} " if under else ""
-        fo.write(f"# rocprofv3 --kernel-trace of `python3 bench.py {sw}--no-cpu-baseline`: duration of every dispatch, ms, in launch order\n")
+        fo.write(f"# rocprofv3 --kernel-trace of `python3 bench.py {sw}--no-cpu-baseline --no-other-configs`: duration of every dispatch, ms, in launch order\n")
+        fo.write("# (headline kernel: first call, second call, the warm-up steps, the timed steps, then 1 + steps launches with MDT_NO_ORDER=1)\n")
         if under:
             fo.write(f"# the same run's own line: ms_per_step {under['ms_per_step']:.3f}, roofline.kernel_ms (HIP events) {under['roofline']['kernel_ms']:.3f}\n")
         for k, v in disp.items():
             d = [x[1] for x in sorted(v)]
             fo.write(f"{k}: n={len(d)} mean={sum(d) / len(d):.3f} min={min(d):.3f} max={max(d):.3f}\n  " + " ".join(f"{x:.2f}" for x in d) + "\n")
             if "small" in k and "double" in k and under and len(d) >= under["steps"] + under["warmup"]:
-                w0 = under["warmup"]
+                w0 = under["warmup"] + (2 if "first_call_ms" in under else 0)
                 t = d[w0:w0 + under["steps"]]
                 fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)}): mean {sum(t) / len(t):.3f} ms\n")
 for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "phase_cfg3_rank", "phase_cfg3_fold", "phase_cfg5_rank", "phase_cfg5_fold",
