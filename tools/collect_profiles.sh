@@ -34,6 +34,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_ca
 for cfg in cfg2:10000 cfg3:1000 cfg5:12500; do
   bash $R/tools/pmc_phases.sh ${cfg%%:*} ${cfg##*:} > $O/pmc_phases_${cfg%%:*}.txt 2>&1
 done
+[ -x $R/tools/mfma_f64_bench ] || hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o $R/tools/mfma_f64_bench $R/tools/mfma_f64_bench.hip
 $R/tools/mfma_f64_bench > $O/mfma_microbench.txt 2>&1
 cd $R
 cat $O/bench.json
