@@ -455,7 +455,8 @@ int ensure_ztab(mdt_ctx* ctx, long long n, int f32, hipStream_t st) {
     if (need > ctx->ztab_cap) {
         if (ctx->ztab) (void)hipFree(ctx->ztab);
         ctx->ztab = nullptr; ctx->ztab_cap = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->ztab, (size_t)need * sizeof(double)));
+        // (+ 32 entries of slack: the fold merge reads the scores of a thread's positions as aligned pairs, past the last rank at the end of a slice)
+        HIP_TRY(hipMalloc((void**)&ctx->ztab, (size_t)(need + 32) * sizeof(double)));
         ctx->ztab_cap = need;
     }
     const int bs = 256;
