@@ -1466,3 +1466,40 @@ def test_one_chunk_path_matches_the_general_path(pkg, methods, monkeypatch):
     for u, v in zip(a, b):
         assert np.array_equal(u, v, equal_nan=True)
     assert pkg.status() in (0, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["auto", "big"])
+def test_constant_chains_in_moments_only_rounds(pkg, monkeypatch, cfg):
+    """rhat(kind = rank / bulk / tail) and rhat_nested from the moments-only rounds (no scores written): a split chain whose
+    scores are all the same bits has variance EXACTLY 0 -- the rounds take the or / and of the scores only where a tie group
+    of at least niter members exists (round 4).  Constant chains, constant parameters, a constant chain whose value also
+    occurs in the other chains, and a chain that is constant but for one draw, in both geometries; against the oracle and
+    bit-equal to the scores-writing path (ess_rhat)."""
+    import warnings
+    from oracle import c_oracle as co
+    if cfg != "auto":
+        monkeypatch.setenv("MDT_CONFIG", cfg)
+    rng = np.random.default_rng(404)
+    D, C = 7000, 4
+    x = rng.standard_normal((D, C, 7))
+    x[:, 1, 0] = 0.25                                   # one constant chain (both its halves)
+    x[: D // 2, 2, 1] = -0.5                            # one constant split chain
+    x[:, :, 2] = 3.0                                    # constant parameter: NaN
+    x[:, 0, 3] = x[5, 1, 3]                             # a constant chain whose value also sits in another chain
+    x[:, 3, 4] = 1.0
+    x[17, 3, 4] = 1.0000001                             # constant but for one draw: not constant
+    x[:, :, 5] = np.round(x[:, :, 5], 1)                # heavy ties, no constant chain
+    xd = dev(x)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kind in ("rank", "bulk", "tail"):
+            got = host(pkg.rhat(xd, kind=kind))
+            want = co.ess_rhat(x, kind=kind)[1]
+            assert_close(got, want, RTOL64, f"rhat {kind} {cfg}")
+            both = host(pkg.ess_rhat(xd, kind=kind)[1])
+            assert np.array_equal(got, both, equal_nan=True), kind  # (the scores-writing path: same moments, same bits)
+        ids = np.repeat(np.arange(1, 3), C // 2)
+        inds = np.arange(C).reshape(2, C // 2).T        # column k: the chains of superchain k
+        got = host(pkg.rhat_nested(xd, ids, kind="rank"))
+        assert_close(got, co.rhat_nested(x, inds, kind="rank"), RTOL64, f"nested {cfg}")
