@@ -507,8 +507,8 @@ def main():
                 "kernel_ms": kernel_ms,
                 "algorithmic_bytes_per_param": b_alg,
                 "limiter_note": ("the nominal bound of this scan/sort/reduce path is HBM (SURVEY.md 8d); what limits the launch in practice is instruction "
-                                 "issue and dependent LDS / L2 round trips between barriers -- about 487 vector instructions per element, vector ALUs "
-                                 "about 60 % busy at four waves per SIMD (profiles/r04c_pmc_phases_cfg2.txt, DESIGN.md 5d)"),
+                                 "issue and dependent LDS / L2 round trips between barriers -- about 490 vector instructions per element, vector ALUs "
+                                 "about 60 % busy at four waves per SIMD (profiles/r04f_pmc_phases_cfg2.txt, DESIGN.md 5d)"),
             },
         }
         # traffic per launch from the committed PMC profile of this same command, if present
