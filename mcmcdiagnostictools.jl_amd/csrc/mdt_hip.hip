@@ -40,6 +40,7 @@
 // the register-hungry lag products lose more than the count / histogram passes gain.  Not instantiated.)
 #include "mdt_hip.h"
 #include "mdt_beta.hpp"
+#include "mdt_wave.h"
 
 #include <cmath>
 #include <cstdio>
@@ -145,6 +146,11 @@ struct mdt_ctx {
     unsigned int* order_sorted = nullptr; // work area of order_kernel: the parameters by decreasing cost
     long long order_cap = 0;
     long long order_P = -1;             // the order on the device is a permutation of [0, order_P); -1: none
+    // wave-per-parameter kernel (mdt_wave.hip): per-wave scratch, and the parameters it leaves to the general kernel
+    void* wv_scratch = nullptr;
+    size_t wv_cap = 0;
+    unsigned int* fb_list = nullptr;
+    long long fb_cap = 0;
     KP* kp_ring = nullptr;              // device copies of the kernel parameters, one slot per launch
     unsigned kp_next = 0;
     int* chain_inds = nullptr;
@@ -357,9 +363,17 @@ __global__ void kp_setup_kernel(KP* slot, KP v, int* status, int keep_status) {
         *slot = v;
         // the flags of the previous launch become sticky (mdt_ctx_status) before this launch starts with a clean word;
         // a second pass keeps the word: its caller reports the flags of both passes
-        if (!keep_status) { status[2] |= status[0]; status[0] = 0; }
+        // (keep_status bit 1: the launch works off the list the wave-per-parameter kernel in front of it left: its count stays)
+        if (!(keep_status & 1)) { status[2] |= status[0]; status[0] = 0; }
+        if (!(keep_status & 2)) status[3] = 0;
         status[1] = 0;
     }
+}
+
+// The parameters the wave-per-parameter kernel left behind (status[3] of them, listed in the `order` table of this slot)
+// become the tickets of the general kernel queued behind it: its parameter count is only known on the device.
+__global__ void fb_patch_kernel(KP* slot, const int* status) {
+    if (threadIdx.x == 0) slot->P = status[3];
 }
 
 // the same bookkeeping for the entry points that do not go through mdt_kernel (gelmandiag)
@@ -403,6 +417,14 @@ __global__ __launch_bounds__(1024) void order_kernel(const unsigned int* __restr
 }
 
 constexpr unsigned KP_RING = 64;
+
+// Test and A/B switches (MDT_CONFIG, MDT_WAVE, MDT_RANK_VARIANT, ...) change which of several bit-compatible paths serves a
+// request; some of them change the last bits of an ESS.  A stray variable in a user's shell must not do that: the switches
+// are read only when MDT_TEST_HOOKS=1 was set when the library was first used (tests/conftest.py sets it).
+const char* hook(const char* name) {
+    static const bool on = [] { const char* e = getenv("MDT_TEST_HOOKS"); return e && *e && strcmp(e, "0") != 0; }();
+    return on ? getenv(name) : nullptr;
+}
 
 int fail(mdt_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
@@ -531,8 +553,8 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // device in blocks, block i + 1 over PCIe while block i computes (the stage request returns arrays of the size of x:
     // not this way)
     if (a->location == MDT_HOST && rq.mode != 3 && ps >= (C - 1) * cs + D) {
-        const char* emin = getenv("MDT_HOST_PIPE_MIN"); // bytes (tests: 1)
-        const char* eblk = getenv("MDT_HOST_PIPE_BLOCKS");
+        const char* emin = hook("MDT_HOST_PIPE_MIN"); // bytes (tests: 1)
+        const char* eblk = hook("MDT_HOST_PIPE_BLOCKS");
         const size_t xb = (size_t)((P - 1) * ps + (C - 1) * cs + D) * tsize(a->dtype);
         const size_t min_bytes = emin ? (size_t)atoll(emin) : ((size_t)128 << 20);
         long long nb = eblk ? atoll(eblk) : (long long)(xb / ((size_t)192 << 20));
@@ -566,13 +588,13 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool fft = a->autocov == MDT_AUTOCOV_FFT && rq.want_ess && ess_ok;
     // geometry: two 512-thread workgroups per CU (80 KiB of LDS each) whenever the request fits their
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
-    const bool fft_lds = fft && getenv("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
+    const bool fft_lds = fft && hook("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
-                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * (getenv("MDT_SMALL_ROUNDS") ? atoll(getenv("MDT_SMALL_ROUNDS")) : 64);
+                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * (hook("MDT_SMALL_ROUNDS") ? atoll(hook("MDT_SMALL_ROUNDS")) : 64);
     // short slices: four 256-thread workgroups per CU (40 KiB of LDS each) -- a parameter of a few thousand values
     // is mostly barrier and latency chains, which twice as many resident workgroups hide twice as well
     int force_cfg = ctx->force_cfg; // MDT_CONFIG is honoured per request (tests switch it between calls)
-    if (const char* c = getenv("MDT_CONFIG")) force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
+    if (const char* c = hook("MDT_CONFIG")) force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
     else force_cfg = 0;
     // (measured: 1000 x 4 x 100 000 19.5 ms against 31.8 with two 512-thread workgroups per CU, 200 x 4 x 500 000 57 against
     // 132, 1000 x 12 x 30 000 28.4 against 36.1; no gain once a split chain no longer fits the z-series buffer)
@@ -584,13 +606,24 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // 16.88, 2000 x 2 x 50 000 7.17 / 8.04, 600 x 4 x 100 000 13.72 / 13.76, 500 x 4 x 100 000 13.36 / 12.77: it pays where the
     // 256-thread geometry needs two rounds (more than 2560 values) and loses below, where four small workgroups per CU hide the
     // per-parameter latency chains better than two large ones.  MDT_ONECHUNK=0: never, 2: wherever it can run (tests, A/B timing)
-    const int oc_env = getenv("MDT_ONECHUNK") ? atoi(getenv("MDT_ONECHUNK")) : 1;
+    const int oc_env = hook("MDT_ONECHUNK") ? atoi(hook("MDT_ONECHUNK")) : 1;
     const bool onechunk = oc_env != 0 && small_fits && rq.mode == 0 && !rq.basic &&
                           rq.est == 0 && n <= (long long)mdt_small::OC_MAX && (oc_env == 2 || n > (long long)mdt_tiny::QCH) && D % s == 0 && m <= 8 &&
                           niter >= 64 && !fft_lds && niter + maxlag + 80 <= mdt_small::SZ && maxlag < mdt_small::SZ_EDGE &&
-                          (rq.need_eb || rq.need_rb) && !(getenv("MDT_RANK_VARIANT") && atoi(getenv("MDT_RANK_VARIANT")) != 2);
+                          (rq.need_eb || rq.need_rb) && !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2);
     const bool tiny = force_cfg == 0 ? (tiny_fits && !onechunk) : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
+    // Short slices, one parameter per WAVE (mdt_wave.hip): rank-normalised requests (kinds bulk / tail / rank and the fused one) on
+    // slices of 256 ... 4096 values in at most 16 split chains of 8 ... 640 draws, effective maxlag <= 255, AutocovMethod or
+    // FFTAutocovMethod (evaluated from lag products, as everywhere).  Parameters it cannot serve (a NaN, an infinity, a point mass
+    // larger than a round, many ties among the folded values) come back in a list and the general kernel, queued behind it, works
+    // that list off.  MDT_WAVE=0: never, 2: wherever it can run (tests, A/B timing; needs MDT_TEST_HOOKS=1 like every switch)
+    const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
+    const bool wave = wave_env != 0 && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
+                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) &&
+                      n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER &&
+                      maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&
+                      !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2) && P < 0x7FFFFFFFLL;
 
     MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
@@ -633,6 +666,29 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const long long wgs = tiny ? 2LL * ctx->grid : (small ? ctx->grid : ctx->grid / 2);
     int rc = ensure_scratch(ctx, (many && 2 * m > n) ? 2 * m : n, wgs); // (many split chains: their 2 m moments live in the scratch of the sorted copy)
     if (rc) return rc;
+    mdtw::Geo wgeo{};
+    int wave_wgs = 0;
+    if (wave) {
+        wgeo = mdtw::geometry(n, f32 ? 1 : 0);
+        const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        wave_wgs = (int)std::min<long long>(ncu, (P + wgeo.waves - 1) / wgeo.waves);
+        // (the scratch is sized for a full grid: the same buffer serves every request of the shape)
+        const size_t need = mdtw::scratch_bytes(wgeo, (long long)ncu * wgeo.waves);
+        if (need > ctx->wv_cap) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->wv_scratch) (void)hipFree(ctx->wv_scratch);
+            ctx->wv_scratch = nullptr; ctx->wv_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->wv_scratch, need));
+            ctx->wv_cap = need;
+        }
+        if (P > ctx->fb_cap) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->fb_list) (void)hipFree(ctx->fb_list);
+            ctx->fb_list = nullptr; ctx->fb_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->fb_list, (size_t)P * sizeof(unsigned int)));
+            ctx->fb_cap = P;
+        }
+    }
     if (strided) {
         const long long need = wgs * ctx->n_pad;
         if (need > ctx->xc_elems) {
@@ -664,7 +720,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     memset(&kp, 0, sizeof(kp));
     kp.x = dx;
     kp.cstride = cs; kp.pstride = ps; kp.strided = strided ? 1 : 0; kp.xcbuf = ctx->xcbuf;
-    kp.ibits = ctx->ibits; kp.ibits_stride = getenv("MDT_NO_IBITS") ? 0 : ctx->ibits_stride; // (MDT_NO_IBITS: indicators from x itself; tests, A/B timing)
+    kp.ibits = ctx->ibits; kp.ibits_stride = hook("MDT_NO_IBITS") ? 0 : ctx->ibits_stride; // (MDT_NO_IBITS: indicators from x itself; tests, A/B timing)
     kp.D = D; kp.C = C; kp.P = P; kp.n = n;
     kp.niter = niter; kp.s = (int)s; kp.rem = (int)(D % s); kp.m = (int)m;
     kp.mode = rq.mode; kp.basic = rq.basic; kp.est = rq.est; kp.fft_lds = fft_lds ? 1 : 0;
@@ -709,7 +765,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.r2buf = ctx->r2buf; kp.zbuf = ctx->zbuf; kp.binbuf = ctx->binbuf; kp.n_pad = ctx->n_pad;
     kp.xsbuf = ctx->xsbuf; kp.bsbuf = ctx->bsbuf;
     {
-        const char* rv = getenv("MDT_RANK_VARIANT");
+        const char* rv = hook("MDT_RANK_VARIANT");
         // rounds re-stream the slice for small slices (<= 16-bit slots, few rounds); beyond, the two-level
         // partitioned variant (O(n) traffic, bins re-cut per round; it falls back to the single-level
         // partitioned variant 1 on a huge point mass); MDT_RANK_VARIANT forces one (tests, A/B timing)
@@ -732,9 +788,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         if (need_rank && n > (long long)mdt_big::MAXROUNDS * chunk)
             return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
     }
-    { const char* fm = getenv("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
-    { const char* wo = getenv("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
-    { const char* pe = getenv("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
+    { const char* fm = hook("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
+    { const char* wo = hook("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
+    { const char* pe = hook("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
     kp.onechunk = onechunk ? 1 : 0;
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];
@@ -746,7 +802,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.prof = ctx->prof;
     // ticket order: by the durations the previous launch with as many parameters measured; this launch measures again
     kp.order = nullptr; kp.cost = nullptr;
-    const bool lpt = P > wgs && P < 0xFFFFFFFFLL && !getenv("MDT_NO_ORDER"); // (one ticket per workgroup at most: nothing to order)
+    const bool lpt = !wave && P > wgs && P < 0xFFFFFFFFLL && !hook("MDT_NO_ORDER"); // (one ticket per workgroup at most: nothing to order)
     if (lpt) {
         if (P > ctx->order_cap) {
             if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
@@ -773,15 +829,30 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // scalar loads on demand instead of pinning ~60 SGPRs for its whole life
     const unsigned si = ctx->kp_next++ % KP_RING;
     KP* slot = ctx->kp_ring + si;
-    hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
+    if (wave) {
+        // the wave-per-parameter kernel over all parameters, then the general kernel over the list it left (its length is only
+        // known on the device: the second slot's parameter count is patched there); both on the stream, nothing returns to the host
+        hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status & 1);
+        mdtw::set_debug_buf(hook("MDT_WAVE_DBG") ? (unsigned*)strtoull(hook("MDT_WAVE_DBG"), nullptr, 0) : nullptr);
+        mdtw::set_debug_stop(hook("MDT_WAVE_STOP") ? atoi(hook("MDT_WAVE_STOP")) : 0);
+        mdtw::launch(st, (const KP*)slot, f32 ? 1 : 0, wgeo, wave_wgs, ctx->wv_scratch, ctx->fb_list, ctx->status + 3);
+        KP kb = kp;
+        kb.order = ctx->fb_list; kb.cost = nullptr; kb.P = 0;
+        KP* slot2 = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
+        hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot2, kb, ctx->status, 3);
+        hipLaunchKernelGGL(fb_patch_kernel, dim3(1), dim3(64), 0, st, slot2, (const int*)ctx->status);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot2);
+    } else {
+        hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status & 1);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot);
+    }
     if (lpt) { // (same stream: it runs when every duration is in, and before the next launch reads the order)
         // the cheapest 2 x wgs parameters close the launch in sorted order; the others are walked with a stride near head / 7.3
         // (a handful of tickets per workgroup -- BASELINE config 3 has 3.9 --: the makespan is a bin-packing problem, the whole
         // sequence is sorted, longest first)
         long long tail = P <= 6 * wgs ? P : std::min<long long>(P, 2 * wgs), head = P - tail, stride = 1;
-        if (const char* e = getenv("MDT_ORDER_TAIL")) { tail = std::min<long long>(P, std::max<long long>(0, atoll(e))); head = P - tail; } // (A/B timing)
-        if (head > 2 && !getenv("MDT_ORDER_PURE")) {
+        if (const char* e = hook("MDT_ORDER_TAIL")) { tail = std::min<long long>(P, std::max<long long>(0, atoll(e))); head = P - tail; } // (A/B timing)
+        if (head > 2 && !hook("MDT_ORDER_PURE")) {
             stride = std::max<long long>(2, (long long)((double)head / 7.3));
             auto gcd = [](long long a, long long b) { while (b) { const long long t = a % b; a = b; b = t; } return a; };
             while (gcd(stride, head) != 1) ++stride;
@@ -1010,8 +1081,8 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { delete ctx; return MDT_ERUNTIME; }
     ctx->num_cu = prop.multiProcessorCount;
     ctx->grid = 2 * (ctx->num_cu > 0 ? ctx->num_cu : 256); // two 512-thread or one 1024-thread workgroup per CU (LDS-bound)
-    if (const char* g = getenv("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = 2 * v; } // diagnostics: workgroups of the big geometry
-    if (const char* c = getenv("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
+    if (const char* g = hook("MDT_GRID")) { const int v = atoi(g); if (v > 0) ctx->grid = 2 * v; } // diagnostics: workgroups of the big geometry
+    if (const char* c = hook("MDT_CONFIG")) ctx->force_cfg = !strcmp(c, "big") ? 1 : (!strcmp(c, "small") ? 2 : (!strcmp(c, "tiny") ? 3 : 0));
     if (hipMalloc((void**)&ctx->status, 4 * sizeof(int)) != hipSuccess || hipMemset(ctx->status, 0, 4 * sizeof(int)) != hipSuccess) { delete ctx; return MDT_ENOMEM; }
     // > 64 KB of dynamic LDS needs the opt-in, per kernel variant
     const void* kerns[] = {(const void*)mdt_big::mdt_kernel<double>, (const void*)mdt_big::mdt_kernel<float>,
@@ -1026,12 +1097,17 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
             return MDT_ERUNTIME;
         }
     }
+    if (mdtw::prepare_device() != 0) {
+        (void)hipFree(ctx->status);
+        delete ctx;
+        return MDT_ERUNTIME;
+    }
     if (hipMalloc((void**)&ctx->kp_ring, KP_RING * sizeof(KP)) != hipSuccess) {
         (void)hipFree(ctx->status);
         delete ctx;
         return MDT_ENOMEM;
     }
-    if (getenv("MDT_PROF")) {
+    if (hook("MDT_PROF")) {
         if (hipMalloc((void**)&ctx->prof, (size_t)ctx->grid * 2 * 16 * sizeof(unsigned long long)) != hipSuccess ||
             hipMemset(ctx->prof, 0, (size_t)ctx->grid * 2 * 16 * sizeof(unsigned long long)) != hipSuccess) {
             (void)hipFree(ctx->status);
@@ -1062,6 +1138,8 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->prof) (void)hipFree(ctx->prof);
     if (ctx->kp_ring) (void)hipFree(ctx->kp_ring);
+    if (ctx->wv_scratch) (void)hipFree(ctx->wv_scratch);
+    if (ctx->fb_list) (void)hipFree(ctx->fb_list);
     if (ctx->chain_inds) (void)hipFree(ctx->chain_inds);
     if (ctx->ess_tmp) (void)hipFree(ctx->ess_tmp);
     if (ctx->tpos_arr) (void)hipFree(ctx->tpos_arr);

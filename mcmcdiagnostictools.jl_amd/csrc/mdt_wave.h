@@ -1,0 +1,35 @@
+// mdt_wave.h -- host-side interface of the wave-per-parameter kernel (mdt_wave.hip), used by mdt_hip.hip.
+// Internal to libmdt_hip.so: nothing here is part of the C-ABI (include/mdt_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "mdt_kp.hpp"
+
+namespace mdtw {
+
+// limits of the path (everything else is served by the workgroup-per-parameter kernels of mdt_device.hpp)
+constexpr int WV_MAXN = 4096;     // draws * chains
+constexpr int WV_MAXM = 16;       // chains * split_chains
+constexpr int WV_NITER = 640;     // draws / split_chains
+constexpr int WV_MAXLAG = 255;    // effective maxlag
+
+// per-launch geometry, fixed by the slice size and the element type
+struct Geo {
+    int waves;          // waves per workgroup (one workgroup per CU)
+    int tab_bytes;      // LDS bytes of the normal-score table shared by the workgroup
+    int lds_bytes;      // dynamic LDS of the launch
+    long long npad;     // elements of per-wave scratch
+};
+Geo geometry(long long n, int f32);
+// bytes of per-wave scratch in global memory for `waves_total` waves
+size_t scratch_bytes(const Geo& g, long long waves_total);
+void set_debug_buf(unsigned* host_pinned); // diagnostics: progress word per wave
+void set_debug_stop(int k); // diagnostics: parameters end after phase k (0 = never)
+int prepare_device(); // once per device, under its hipSetDevice: 0 = ok
+// Queue the kernel on `st`: workgroups x waves tickets over kp->P parameters.  `kp_slot` is the device copy of the parameter
+// block (kp_setup_kernel wrote it on the same stream).  Parameters the path cannot serve (a non-finite value, a point mass
+// larger than a round, too many ties among the folded values) are appended to fb_list, their count to *fb_count.
+void launch(hipStream_t st, const mdtc::KP* kp_slot, int f32, const Geo& g, int workgroups, void* scratch,
+            unsigned* fb_list, int* fb_count);
+
+} // namespace mdtw

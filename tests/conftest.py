@@ -5,6 +5,10 @@ import sys
 import numpy as np
 import pytest
 
+# the library reads its test / A/B switches (MDT_CONFIG, MDT_WAVE, MDT_RANK_VARIANT, ...) only behind this gate, sampled when it
+# is first used: a stray variable in a user's shell never changes which path serves a request
+os.environ.setdefault("MDT_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1503,3 +1503,117 @@ def test_constant_chains_in_moments_only_rounds(pkg, monkeypatch, cfg):
         inds = np.arange(C).reshape(2, C // 2).T        # column k: the chains of superchain k
         got = host(pkg.rhat_nested(xd, ids, kind="rank"))
         assert_close(got, co.rhat_nested(x, inds, kind="rank"), RTOL64, f"nested {cfg}")
+
+
+def _wave_case_array(rng):
+    """the data flavours of the one-chunk test, one per parameter (1000 draws x 4 chains)"""
+    x = ar1(0.6, 1000, 4, 16, rng)
+    x[:, :, 1] = rng.standard_normal((1000, 4))            # IID
+    x[:, :, 2] = np.round(x[:, :, 2], 1)                   # heavy ties: point masses larger than a round -> the general kernel
+    x[:, 2, 3] = 0.25                                      # a constant chain: W > 0, exact zeros in its deviations
+    x[:, :, 4] = 1.5                                       # a constant parameter: NaN, NaN
+    x[5, 1, 5] = np.inf; x[6, 1, 5] = -np.inf              # infinities -> the general kernel
+    x[7, 0, 6] = 0.0; x[8, 0, 6] = -0.0                    # signed zeros tie
+    x[:, :, 7] = np.exp(3.0 * x[:, :, 7])                  # heavy right tail: crowded bins
+    x[rng.random((1000, 4)) < 0.4, 8] = 0.25               # a point mass holding 40 % of the slice
+    x[:, :, 9] += 3.0 * rng.standard_normal((1, 4))        # chains that do not agree: every lag sweep
+    x[:, :, 10] = ar1(0.97, 1000, 4, 1, rng)[:, :, 0]      # slowly mixing: several sweeps
+    x[:, :, 11] = -x[:, :, 11]
+    x[1::2, :, 12] = -x[0:-1:2, :, 12]                     # antithetic: ESS at the cap
+    x[:, :, 13] = np.round(x[:, :, 13], 3)                 # a few ties: half-integer ranks, equals among the folds
+    x[::2, :, 14] = -x[1::2, :, 14]                        # symmetric pairs: every fold has an equal
+    x[17, 2, 15] = np.nan                                  # a NaN -> the general kernel
+    return x
+
+
+def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
+    """Round 5: slices of 256 ... 4096 values run ONE PARAMETER PER WAVE (csrc/mdt_wave.hip): no workgroup barrier, the slice
+    class-sorted through a per-wave scratch, ranked round by round in ~11 KB of LDS, fold merge, z-series staged per split
+    chain, lag products on the matrix pipe, popcount indicators.  MDT_WAVE=0 sends the same request down the
+    workgroup-per-parameter kernels: R-hat must be the same BITS (same fixed-point moments, same expressions), ESS within
+    1e-9 (other summation order of the lag products); parameters the path cannot serve (NaN, infinities, point masses, many
+    tied folds) come back through the general kernel inside the same request; the oracle agrees with both."""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(505)
+    x = _wave_case_array(rng)
+    shapes = [("1000x4", x), ("997x4", x[:997]), ("500x4", x[:500]), ("250x4", x[:250]), ("64x4", x[:64]), ("f32", x.astype(np.float32)),
+              ("640x6", np.concatenate([x[:640], x[:640, :2]], axis=1)), ("250x8", np.concatenate([x[:250], x[250:500]], axis=1)),
+              ("1000x1", x[:, :1]), ("1280x3", np.concatenate([x, x[:280]], axis=0)[:, :3])]
+
+    def run_all(xd, s):
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out += [("fused%d" % i, host(o)) for i, o in enumerate(pkg.bulk_tail(xd, split_chains=s))]
+            for kind in ("bulk", "tail", "rank"):
+                r = pkg.ess_rhat(xd, kind=kind, split_chains=s, autocov_method=methods["direct"], maxlag=250 if kind != "rank" else 40)
+                out += [(kind + " ess", host(r.ess)), (kind + " rhat", host(r.rhat))]
+            out.append(("rhat only", host(pkg.rhat(xd, split_chains=s))))
+            out.append(("rhat tail", host(pkg.rhat(xd, kind="tail", split_chains=s))))
+            out.append(("ess tail rel", host(pkg.ess(xd, kind="tail", split_chains=s, relative=True))))
+            out.append(("fft ess", host(pkg.ess(xd, kind="bulk", split_chains=s, autocov_method=methods["fft"]))))
+            out.append(("fft ess tail", host(pkg.ess(xd, kind="tail", split_chains=s, autocov_method=methods["fft"], maxlag=7))))
+        return out
+
+    for what, xs in shapes:
+        for s in (2, 1, 3):
+            D, C = xs.shape[:2]
+            if C * s > 16 or D // s > 640 or D // s < 8 or D * C < 256:
+                continue
+            xd = dev(xs)
+            monkeypatch.setenv("MDT_WAVE", "2")
+            a = run_all(xd, s)
+            monkeypatch.setenv("MDT_WAVE", "0")
+            b = run_all(xd, s)
+            monkeypatch.delenv("MDT_WAVE")
+            for (ka, va), (kb, vb) in zip(a, b):
+                if "rhat" in ka or ka in ("fused2", "fused3"):
+                    assert np.array_equal(va, vb, equal_nan=True), (what, s, ka, va, vb)
+                else:
+                    assert_close(va, vb, 1e-9 if xs.dtype == np.float64 else 2e-6, f"{what} s={s} {ka}")
+            if xs.dtype == np.float64:
+                want = co.bulk_tail(xs, split_chains=s)
+                for i in range(4):
+                    assert_close(a[i][1], want[i], RTOL64, f"{what} s={s} oracle {i}")
+    assert pkg.status() in (0, 2)
+
+
+@pytest.mark.parametrize("name", ["cfg1_randn_1000x4x10", "ties_200x4x6", "odd_1001x3x3", "ar1_500x4x10", "onechain_400x1x3"])
+def test_wave_path_on_the_golden_vectors(pkg, methods, monkeypatch, name):
+    """the committed golden vectors through the wave-per-parameter kernel, forced wherever it can run (every kind x method x
+    split x maxlag of the fixture; what it cannot serve -- raw draws, BDA, tiny slices -- takes the general kernels as always)"""
+    import warnings
+    monkeypatch.setenv("MDT_WAVE", "2")
+    g = load_golden(name)
+    xd = dev(g["x"])
+    for ke, kr, kind, method, s, ml in _keys(g):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            S, R = pkg.ess_rhat(xd, kind=kind, autocov_method=methods[method], split_chains=s, maxlag=ml)
+        assert_close(host(S), g[ke], RTOL64, f"{name} {ke}")
+        assert_close(host(R), g[kr], RTOL64, f"{name} {kr}")
+
+
+def test_switches_need_the_test_hooks_gate(pkg):
+    """The library reads MDT_WAVE, MDT_CONFIG, MDT_RANK_VARIANT ... only when MDT_TEST_HOOKS=1 was set when it was first used
+    (tests/conftest.py does that): a child process WITHOUT the gate must give the default path's bits whatever the switches say."""
+    import subprocess, sys, os, json
+    code = r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, %r)
+import __graft_entry__ as g
+pkg = g.load_package()
+rng = np.random.default_rng(7)
+x = rng.standard_normal((8, 4, 1000)).cumsum(axis=2) * 0.05 + rng.standard_normal((8, 4, 1000))
+xd = torch.from_numpy(x).cuda().permute(2, 1, 0)
+print(json.dumps([o.cpu().numpy().tolist() for o in pkg.bulk_tail(xd)]))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env_extra in ({}, {"MDT_WAVE": "0", "MDT_CONFIG": "big", "MDT_RANK_VARIANT": "1", "MDT_ONECHUNK": "0", "MDT_FOLD_MERGE": "0"}):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("MDT_")}
+        env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
