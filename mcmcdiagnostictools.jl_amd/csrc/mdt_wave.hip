@@ -57,8 +57,16 @@ constexpr int OFF_LAGA = OFF_SP;                       // (series phase, over th
 constexpr int OFF_CCUR = OFF_IW + 128 * 8;             // unsigned ccur[128]: class histogram, then cursors
 constexpr int OFF_RTAB = OFF_CCUR + 128 * 4;           // unsigned short rtab[MAXROUNDS + 2]: first class of every round
 constexpr int OFF_OST = ((OFF_RTAB + (MAXROUNDS + 2) * 2 + 7) / 8) * 8; // double ostat[8]
-constexpr int OFF_MEAN = OFF_OST + 8 * 8;              // double mean_j[16], var_j[16], mu_j[16]
-constexpr int OFF_VIEW = ((OFF_MEAN + 3 * WV_MAXM * 8 + 15) / 16) * 16;
+constexpr int OFF_ORK = OFF_OST + 8 * 8;               // unsigned orank[8]: doubled tied rank of every captured order statistic
+constexpr int OFF_MEAN = OFF_ORK + 8 * 4;              // double mean_j[16], var_j[16], mu_j[16]
+constexpr int OFF_WS = OFF_MEAN + 3 * WV_MAXM * 8;     // struct WS: what the phases of a parameter hand to each other (wave-uniform)
+constexpr int WS_BYTES = 192;
+constexpr int OFF_PROF = OFF_WS + WS_BYTES;            // (diagnostics build WV_PROF) unsigned long long prof[16]: cycles per phase
+#ifdef WV_PROF
+constexpr int OFF_VIEW = ((OFF_PROF + 17 * 8 + 15) / 16) * 16;
+#else
+constexpr int OFF_VIEW = ((OFF_PROF + 15) / 16) * 16;
+#endif
 static_assert(OFF_LAGA + 256 * 8 <= OFF_CCUR, "lag table lives over the splitter tables");
 // rank view
 constexpr int OFF_VAL = OFF_VIEW;                      // double val[WR]; during passes A / B: uint8 cls[WV_MAXN]
@@ -68,27 +76,30 @@ constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
 static_assert(WV_MAXN <= WR * 8, "the time-order class bytes of passes A / B live in the image");
 // fold view
-constexpr int OFF_FA = OFF_VIEW;                       // double fa[FT + 2], fb[FT + 2]: entry q + 1 = staged member q (q = -1 .. FT)
-constexpr int OFF_FB = OFF_FA + (FT + 2) * 8;
-constexpr int OFF_SA = OFF_FB + (FT + 2) * 8;          // uint8 sa[FT + 2], sb[FT + 2]: their split-chain slots
-constexpr int OFF_SB = OFF_SA + ((FT + 2 + 7) / 8) * 8;
-constexpr int OFF_FACC = OFF_SB + ((FT + 2 + 7) / 8) * 8; // int64 facc[2][16][8]
+constexpr int FE = FT + 2;                             // staged entries of a piece: the member in front of it, FT members at most, the member behind it
+constexpr int OFF_FA = OFF_VIEW;                       // double fa[FE], fb[FE]: entry e = member e - 1 of the tile's piece
+constexpr int OFF_FB = OFF_FA + FE * 8;
+constexpr int OFF_SA = OFF_FB + FE * 8;                // uint8 sa[FE], sb[FE]: their split-chain slots
+constexpr int OFF_SB = OFF_SA + ((FE + 7) / 8) * 8;
+constexpr int OFF_FACC = OFF_SB + ((FE + 7) / 8) * 8;  // int64 facc[2][16][8]
 constexpr int OFF_TOR = OFF_FACC + 2 * WV_MAXM * 8 * 8; // uint64 tor[16], tand[16]
 constexpr int OFF_TCNT = OFF_TOR + 2 * WV_MAXM * 8;    // unsigned tcnt[16], tln, pad
-constexpr int OFF_TVAL = OFF_TCNT + (WV_MAXM + 2) * 4; // double tval[WTCAP]
+constexpr int OFF_TB = OFF_TCNT + (WV_MAXM + 2) * 4;   // unsigned tb[WV_MAXN / FT + 2]: members of A in front of every tile
+constexpr int OFF_TVAL = ((OFF_TB + (WV_MAXN / FT + 2) * 4 + 7) / 8) * 8; // double tval[WTCAP]
 constexpr int OFF_TSL = OFF_TVAL + WTCAP * 8;          // uint8 tsl[WTCAP]
 constexpr int END_FOLD = OFF_TSL + WTCAP;
-// series view
-constexpr int OFF_STG = OFF_VIEW;                      // double stage[STG] (and the 16 x 17 tile staging of a sweep's end)
+// series view: the stage, and behind it (when both fit) the indicator words taken from the ranks while a chain is staged
+constexpr int OFF_STG = OFF_VIEW;                      // double stage[64 nblk + 272] (and the 16 x 17 tile staging of a sweep's end)
 constexpr int END_SER = OFF_STG + STG * 8;
 // indicator view
 constexpr int NWU_MAX = (WV_NITER + 63) / 64 + (WV_MAXLAG >> 6) + 2;
-constexpr int OFF_SB2 = OFF_VIEW;                      // uint64 sb2[2 * 16 * NWU_MAX]
-constexpr int OFF_ICOV = OFF_SB2 + 2 * WV_MAXM * NWU_MAX * 8; // double icov[2][256]
+constexpr int OFF_ICOV = OFF_VIEW;                     // double icov[2][256]
 constexpr int OFF_IMEAN = OFF_ICOV + 2 * 256 * 8;      // double imean[2][16]
-constexpr int END_IND = OFF_IMEAN + 2 * WV_MAXM * 8;
+constexpr int OFF_SB2 = OFF_IMEAN + 2 * WV_MAXM * 8;   // uint64 sb2[2 m nwU] (the unfused form; the fused one sits behind the stage)
+constexpr int END_IND = OFF_SB2 + 2 * WV_MAXM * NWU_MAX * 8;
 constexpr int cmax2(int a, int b) { return a > b ? a : b; }
 constexpr int PERWAVE = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER, END_IND)) + 15) / 16) * 16;
+constexpr int VIEW_BYTES = PERWAVE - OFF_VIEW;
 constexpr int LDS_TOTAL = 160 * 1024;
 
 struct WvArgs {
@@ -102,6 +113,26 @@ struct WvArgs {
     unsigned* dbg;         // diagnostics (MDT_WAVE_DBG = address of a host-pinned array): progress word of every wave, or null
     int stop;              // diagnostics (MDT_WAVE_STOP behind the test-hooks gate): the parameter ends after phase `stop` with NaN outputs; 0 = never
 };
+
+// What the phases of one parameter hand to each other: wave-uniform values in the wave's LDS block.  The phases are separate,
+// non-inlined functions (own register allocation: one function of this size spilled and turned every uniform value into a
+// lane of a spill register); their only argument is the LDS address of the wave's block.
+struct WS {
+    unsigned long long kp;            // const KP* (read through the constant address space)
+    unsigned long long sv, st, ra;    // the wave's scratch
+    unsigned long long xp;            // the parameter's slice
+    unsigned long long dbg;           // progress words, or 0
+    long long p;                      // the parameter
+    double xmin, xmax;
+    double med, qlo, qhi;             // median and the two tail quantiles (values of T)
+    double out[4];                    // ESS bulk, R-hat bulk, ESS tail, R-hat tail
+    unsigned nrounds, anyodd;         // rounds of the ranking; some rank is a half-integer
+    unsigned r2q[2];                  // x <= q  <=>  doubled rank <= r2q (when zq_ok)
+    int fallback, zq_ok, bits_done, stop;
+    unsigned lz, gw;                  // LDS address of the score table; global wave index
+};
+static_assert(sizeof(WS) <= WS_BYTES, "wave state block");
+#define WV_LA __attribute__((address_space(3)))
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -189,6 +220,11 @@ template <typename T>
 using xs_of = typename std::conditional<std::is_same<T, float>::value, float, double>::type;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// LDS atomics on address-space-3 pointers (ds_add_rtn_u32 / ds_add_u64 ...; HIP's atomicAdd takes generic pointers only)
+template <class P, class V> __device__ __forceinline__ V lds_add(P p, V v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class P, class V> __device__ __forceinline__ V lds_or(P p, V v) { return __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+template <class P, class V> __device__ __forceinline__ V lds_and(P p, V v) { return __hip_atomic_fetch_and(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 template <typename T>
 __device__ __forceinline__ void store_out(void* p, long long i, double v) {
     if (p) ((T*)p)[i] = (T)v;
@@ -197,7 +233,8 @@ __device__ __forceinline__ void store_out(void* p, long long i, double v) {
 // W, var+, R-hat from the split-chain means and variances (src/ess_rhat.jl:537-545): the expressions of series_combine
 // (mdt_series.inc), every lane the same value
 struct WB { double W, varp, rhat; };
-__device__ __forceinline__ WB combine_moments(const double* mean_j, const double* var_j, int m, double cf) {
+template <class P>
+__device__ __forceinline__ WB combine_moments(P mean_j, P var_j, int m, double cf) {
     double W = 0.0, mb = 0.0;
     for (int j = 0; j < m; ++j) { W += var_j[j]; mb += mean_j[j]; }
     W /= (double)m;
@@ -212,841 +249,1104 @@ __device__ __forceinline__ WB combine_moments(const double* mean_j, const double
     return o;
 }
 
-#define WDBG(code) do { if (wa.dbg && lane == 0) __hip_atomic_store(wa.dbg + gw, (unsigned)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+
+// ------------------------------------------------------------------ phase plumbing
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
+    const unsigned lo = rflu((unsigned)v), hi = rflu((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+#define WV_PHASE template <typename T> __device__ __attribute__((noinline))
+// every phase starts with this: the wave's LDS block as an address-space-3 pointer held in a scalar register, its state
+// block, the parameter block through the constant address space (scalar loads)
+#define WV_ENTER(wbase_arg)                                                                          \
+    const unsigned wbase = rflu(wbase_arg);                                                          \
+    WV_LA unsigned char* wb = (WV_LA unsigned char*)(unsigned long long)wbase;                       \
+    WV_LA WS* ws = (WV_LA WS*)(wb + OFF_WS);                                                         \
+    const WV_CA KP& kp = *(const WV_CA KP*)rfl64(ws->kp);                                            \
+    const int lane = (int)(threadIdx.x & 63u);                                                       \
+    (void)lane; (void)kp
+#ifdef WV_PROF
+#define WPROF(slot) do { if (lane == 0) { WV_LA unsigned long long* pr_ = (WV_LA unsigned long long*)(wb + OFF_PROF); const unsigned long long t_ = (unsigned long long)__builtin_readcyclecounter(); pr_[slot] += t_ - pr_[16]; pr_[16] = t_; } __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define WPROF(slot) do { } while (0)
+#endif
+
+// row r of the slice (rows of 64 draws; the last row of a chain is partly masked): pooled index of the chain's first draw,
+// this lane's draw, and the (clamped) element offset from the slice
+struct RowAt { unsigned eb, d; long long ad; };
+__device__ __forceinline__ RowAt row_at(unsigned r, unsigned rpc, unsigned D, long long cs, int lane) {
+    const unsigned c = r / rpc, i = r - c * rpc;
+    RowAt o;
+    o.eb = c * D;
+    o.d = 64u * i + (unsigned)lane;
+    o.ad = (long long)c * cs + (o.d < D ? o.d : D - 1u);
+    return o;
+}
+constexpr int UB = 8; // rows per batch of the streaming passes
+
+// ------------------------------------------------------------------ sample -> splitters; pass A: classes, histogram, range; rounds
+WV_PHASE void ph_classify(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA double* sp = (WV_LA double*)(wb + OFF_SP);
+    WV_LA double* iw = (WV_LA double*)(wb + OFF_IW);
+    WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
+    WV_LA unsigned short* rtab = (WV_LA unsigned short*)(wb + OFF_RTAB);
+    WV_LA unsigned char* clsb = (WV_LA unsigned char*)(wb + OFF_VAL);
+    const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
+    const unsigned n = (unsigned)kp.n, D = (unsigned)kp.D, C = (unsigned)kp.C;
+    const long long cs = kp.cstride;
+    const double inf = __builtin_inf();
+    // ---- 128 values spread over the slice, sorted by the wave
+    {
+        double a, b;
+        {
+            const unsigned i0 = (unsigned)lane, i1 = 64u + (unsigned)lane;
+            const unsigned q0 = ((2u * i0 + 1u) * n) >> 8, q1 = ((2u * i1 + 1u) * n) >> 8;
+            const unsigned c0 = q0 / D, c1 = q1 / D;
+            a = (double)xp[(long long)c0 * cs + (q0 - c0 * D)];
+            b = (double)xp[(long long)c1 * cs + (q1 - c1 * D)];
+            a = (a - a == 0.0) ? a : inf;
+            b = (b - b == 0.0) ? b : inf;
+        }
+        for (int k = 2; k <= 64; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const bool lower = (lane & j) == 0;
+                const bool upa = (k == 64) ? true : ((lane & k) == 0);
+                const bool upb = (k == 64) ? false : ((lane & k) == 0);
+                const double oa = __shfl_xor(a, j), ob = __shfl_xor(b, j);
+                a = (lower == upa) ? (oa < a ? oa : a) : (oa > a ? oa : a);
+                b = (lower == upb) ? (ob < b ? ob : b) : (ob > b ? ob : b);
+            }
+        }
+        { const double lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
+        for (int j = 32; j > 0; j >>= 1) {
+            const bool lower = (lane & j) == 0;
+            const double oa = __shfl_xor(a, j), ob = __shfl_xor(b, j);
+            a = lower ? (oa < a ? oa : a) : (oa > a ? oa : a);
+            b = lower ? (ob < b ? ob : b) : (ob > b ? ob : b);
+        }
+        sp[1 + lane] = a;
+        sp[65 + lane] = (lane == 63) ? inf : b; // 127 splitters; the sentinel ends the search
+        ccur[lane] = 0u;
+        ccur[64 + lane] = 0u;
+        lds_fence();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { // inverse widths of the inner classes c = 1 .. 126: [sp[c], sp[c + 1])
+            const int c = lane + 64 * q;
+            if (c >= 1 && c <= 126) {
+                const double wd = sp[c + 1] - sp[c];
+                double v = (wd > 0.0 && wd < inf) ? 1.0 / wd : 0.0;
+                if (!(v < inf)) v = 0.0;
+                iw[c] = v;
+            }
+        }
+    }
+    WPROF(1);
+    // ---- pass A.  A wave has few partners on its SIMD (about three), so every pass keeps its own loads in flight: batch
+    // k + 1 is issued before batch k is worked on.
+    const unsigned rpc = (D + 63u) >> 6, NRW = C * rpc;
+    auto load_batch = [&](unsigned r0, double (&vv)[UB]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const unsigned r = r0 + (unsigned)u;
+            vv[u] = (double)xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad];
+        }
+    };
+    double xmin = inf, xmax = -inf;
+    unsigned bad = 0u;
+    {
+        double vn[UB];
+        load_batch(0u, vn);
+        for (unsigned r0 = 0; r0 < NRW; r0 += UB) {
+            double v[UB];
+            unsigned pos[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { v[u] = vn[u]; pos[u] = 0u; }
+            if (r0 + UB < NRW) load_batch(r0 + UB, vn);
+#pragma unroll
+            for (unsigned step = 64u; step > 0u; step >>= 1) {
+                double t[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) t[u] = sp[pos[u] + step];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) pos[u] += (t[u] <= v[u]) ? step : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const unsigned r = r0 + (unsigned)u;
+                const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
+                if (r < NRW && ra_.d < D) {
+                    bad |= (v[u] - v[u] == 0.0) ? 0u : 1u;
+                    xmin = v[u] < xmin ? v[u] : xmin;
+                    xmax = v[u] > xmax ? v[u] : xmax;
+                    lds_add(&ccur[pos[u]], 1u);
+                    clsb[ra_.eb + ra_.d] = (unsigned char)pos[u];
+                }
+            }
+        }
+    }
+    WPROF(2);
+    bool fallback = __ballot(bad != 0u) != 0ull;
+    unsigned nrounds = 0u;
+    if (!fallback) {
+        xmin = wave_min_d(xmin);
+        xmax = wave_max_d(xmax);
+        lds_fence();
+        const unsigned h0 = ccur[2 * lane], h1 = ccur[2 * lane + 1];
+        const unsigned tot = h0 + h1, incl = wave_incl_scan_u32(tot);
+        const unsigned b0 = incl - tot, b1 = b0 + h0;
+        const unsigned cmax = rflu(wave_max_u32(h0 > h1 ? h0 : h1));
+        if (cmax >= (unsigned)WR) fallback = true; // a point mass (or a crowd) larger than a round
+        else {
+            // rounds = runs of classes whose starts fall into one stretch of Q places: at most Q - 1 + cmax < WR members
+            const unsigned Q = (unsigned)WR - cmax;
+            const unsigned r0 = b0 / Q, r1 = b1 / Q;
+            const unsigned rprev = (unsigned)__shfl_up((int)r1, 1);
+            const unsigned f0 = (lane == 0 || r0 != rprev) ? 1u : 0u, f1 = (r1 != r0) ? 1u : 0u;
+            const unsigned nb = f0 + f1, kin = wave_incl_scan_u32(nb), kx = kin - nb;
+            nrounds = (unsigned)__builtin_amdgcn_readlane((int)kin, 63);
+            if (nrounds > (unsigned)MAXROUNDS) fallback = true;
+            else {
+                lds_fence();
+                ccur[2 * lane] = b0;
+                ccur[2 * lane + 1] = b1;
+                if (f0) rtab[kx] = (unsigned short)(2 * lane);
+                if (f1) rtab[kx + f0] = (unsigned short)(2 * lane + 1);
+                if (lane == 0) {
+                    rtab[nrounds] = (unsigned short)NCLS;
+                    sp[0] = xmin;
+                    const double w0 = sp[1] - xmin, w1 = xmax - sp[127];
+                    const double v0 = (w0 > 0.0 && w0 < inf) ? 1.0 / w0 : 0.0, v1 = (w1 > 0.0 && w1 < inf) ? 1.0 / w1 : 0.0;
+                    iw[0] = (v0 < inf) ? v0 : 0.0;
+                    iw[127] = (v1 < inf) ? v1 : 0.0;
+                }
+            }
+        }
+    }
+    if (lane == 0) { ws->fallback = fallback ? 1 : 0; ws->nrounds = nrounds; ws->xmin = xmin; ws->xmax = xmax; }
+    lds_fence();
+    WPROF(3);
+}
+
+// ------------------------------------------------------------------ pass B: the slice, class-sorted, into the scratch
+WV_PHASE void ph_partition(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
+    WV_LA unsigned char* clsb = (WV_LA unsigned char*)(wb + OFF_VAL);
+    const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
+    WV_GA double* sv = (WV_GA double*)rfl64(ws->sv);
+    WV_GA unsigned* st = (WV_GA unsigned*)rfl64(ws->st);
+    const unsigned D = (unsigned)kp.D, C = (unsigned)kp.C;
+    const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
+    const long long cs = kp.cstride;
+    const unsigned rpc = (D + 63u) >> 6, NRW = C * rpc;
+    auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); }; // src/utils.jl:29-36
+    auto load_batch = [&](unsigned r0, double (&vv)[UB]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const unsigned r = r0 + (unsigned)u;
+            vv[u] = (double)xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad];
+        }
+    };
+    double vn[UB];
+    load_batch(0u, vn);
+    for (unsigned r0 = 0; r0 < NRW; r0 += UB) {
+        double v[UB];
+        unsigned cl[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const unsigned r = r0 + (unsigned)u;
+            const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
+            v[u] = vn[u];
+            cl[u] = clsb[ra_.eb + (ra_.d < D ? ra_.d : D - 1u)];
+        }
+        if (r0 + UB < NRW) load_batch(r0 + UB, vn);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const unsigned r = r0 + (unsigned)u;
+            const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
+            if (r < NRW && ra_.d < D) {
+                const unsigned pos = lds_add(&ccur[cl[u]], 1u);
+                unsigned k = 0u;
+                for (unsigned kk = 1u; kk < s; ++kk) k += (ra_.d >= row0(kk)) ? 1u : 0u;
+                const unsigned c = (r < NRW ? r : NRW - 1u) / rpc;
+                const unsigned slot = (ra_.d < row0(k) + niter) ? c * s + k : 255u; // (255: a row the split drops)
+                sv[pos] = v[u];
+                st[pos] = (ra_.eb + ra_.d) | (slot << 16) | (cl[u] << 24);
+            }
+        }
+    }
+    mem_fence();
+    WPROF(4);
+}
+
+// ------------------------------------------------------------------ the rounds: tied ranks, order statistics, sorted copy
+WV_PHASE void ph_rounds(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA double* sp = (WV_LA double*)(wb + OFF_SP);
+    WV_LA double* iw = (WV_LA double*)(wb + OFF_IW);
+    WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
+    WV_LA unsigned short* rtab = (WV_LA unsigned short*)(wb + OFF_RTAB);
+    WV_LA double* ostat = (WV_LA double*)(wb + OFF_OST);
+    WV_LA unsigned* orank = (WV_LA unsigned*)(wb + OFF_ORK);
+    WV_LA double* val = (WV_LA double*)(wb + OFF_VAL);
+    WV_LA unsigned* tagl = (WV_LA unsigned*)(wb + OFF_TAG);
+    WV_LA unsigned short* binid = (WV_LA unsigned short*)(wb + OFF_BIN);
+    WV_LA unsigned* cnt = (WV_LA unsigned*)(wb + OFF_CNT);
+    WV_GA double* sv = (WV_GA double*)rfl64(ws->sv);
+    WV_GA unsigned* st = (WV_GA unsigned*)rfl64(ws->st);
+    WV_GA unsigned short* ra = (WV_GA unsigned short*)rfl64(ws->ra);
+    const unsigned n = (unsigned)kp.n;
+    const unsigned nrounds = rflu(ws->nrounds);
+    const bool need_med = kp.need_rt != 0;
+    const bool need_q = kp.need_et && kp.ess_ok;
+    const bool need_ra = kp.need_eb || kp.need_rb || need_q; // ranks in time order: the z-series, and the tail indicators
+    unsigned tp[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // 0-based places of the order statistics: median pair first, then the quantile pairs
+    int ntgt = 0;
+    {
+        const unsigned ql0 = (unsigned)(kp.q_j[0] - 1), ql1 = (unsigned)kp.q_j[0], qh0 = (unsigned)(kp.q_j[1] - 1), qh1 = (unsigned)kp.q_j[1];
+        if (need_med && need_q) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; tp[2] = ql0; tp[3] = ql1; tp[4] = qh0; tp[5] = qh1; ntgt = 6; }
+        else if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; ntgt = 2; }
+        else if (need_q) { tp[0] = ql0; tp[1] = ql1; tp[2] = qh0; tp[3] = qh1; ntgt = 4; }
+    }
+    unsigned anyodd = 0u;
+    // members of round r: one contiguous piece [g0, g1) of the class-sorted scratch; the next round's loads are issued as soon
+    // as this round's members sit in the LDS image (their registers are free then)
+    double v[8];
+    unsigned tg[8];
+    auto round_span = [&](unsigned r, unsigned& cA, unsigned& cB, unsigned& g0, unsigned& g1) {
+        cA = rflu((unsigned)rtab[r]); cB = rflu((unsigned)rtab[r + 1]);
+        g0 = cA ? rflu(ccur[cA - 1u]) : 0u;
+        g1 = rflu(ccur[cB - 1u]);
+    };
+    auto issue = [&](unsigned r) {
+        unsigned cA, cB, g0, g1;
+        round_span(r, cA, cB, g0, g1);
+        const unsigned M = g1 - g0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned idx = 64u * i + (unsigned)lane;
+            const unsigned src = g0 + (idx < M ? idx : 0u);
+            v[i] = sv[src < n ? src : n - 1u];
+            tg[i] = st[src < n ? src : n - 1u];
+        }
+    };
+    if (nrounds > 0u) issue(0u);
+    for (unsigned r = 0; r < nrounds; ++r) {
+        unsigned cA, cB, g0, g1;
+        round_span(r, cA, cB, g0, g1);
+        const unsigned M = g1 - g0;
+        const unsigned ncls = cB - cA;
+        const unsigned sh = 31u - (unsigned)__clz((int)((unsigned)NBIN / ncls));
+        const double fsub = (double)((1u << sh) - 1u), fcap = (double)((1u << sh) - 2u);
+#pragma unroll
+        for (int q = 0; q < NBIN / 2 / 64; ++q) cnt[lane + 64 * q] = 0u;
+        unsigned bn[8];
+        {
+            double lo[8], wd[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = iw[cls]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // piecewise-linear fine bin inside the class; sub-bin 0 = equal to the class's lower bound (a constant bin)
+                const unsigned cls = tg[i] >> 24;
+                double f = (v[i] - lo[i]) * wd[i] * fsub;
+                f = f < fcap ? f : fcap;
+                const unsigned sub = (v[i] == lo[i]) ? 0u : 1u + (unsigned)(int)f;
+                bn[i] = (((cls - cA) << sh) + sub) | ((sub == 0u ? 1u : 0u) << 15);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const unsigned b = bn[i] & 0x7FFFu;
+            if (64u * i + (unsigned)lane < M) lds_add(&cnt[b >> 1], 1u << ((b & 1u) << 4));
+        }
+        lds_fence();
+        WPROF(10);
+        { // exclusive prefix over the packed counters: 8 bins per lane
+            unsigned wv[4], s8[8], tot = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv[q] = cnt[4 * lane + q];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const unsigned c8 = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8; }
+            const unsigned incl = wave_incl_scan_u32(tot), bb = incl - tot;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cnt[4 * lane + q] = (bb + s8[2 * q]) | ((bb + s8[2 * q + 1]) << 16);
+        }
+        lds_fence();
+        WPROF(11);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (64u * i + (unsigned)lane < M) {
+                const unsigned b = bn[i] & 0x7FFFu, shb = (b & 1u) << 4;
+                const unsigned pos = (lds_add(&cnt[b >> 1], 1u << shb) >> shb) & 0xFFFFu;
+                val[pos] = v[i];
+                tagl[pos] = tg[i];
+                binid[pos] = (unsigned short)bn[i];
+            }
+        }
+        if (r + 1u < nrounds) issue(r + 1u);
+        lds_fence();
+        WPROF(12);
+        bool tin = false; // any target order statistic in this round?
+#pragma unroll
+        for (int t = 0; t < 6; ++t) tin = tin || (t < ntgt && tp[t] >= g0 && tp[t] < g1);
+        // dense count in slot order: tied rank, place in sorted order
+        for (unsigned i = 0; 64u * i < M; ++i) {
+            const unsigned sl = 64u * i + (unsigned)lane;
+            if (sl < M) {
+                const double x = val[sl];
+                const unsigned tgv = tagl[sl];
+                const unsigned bb = binid[sl], b = bb & 0x7FFFu, bm = b > 0u ? b - 1u : 0u;
+                const unsigned wa_ = cnt[b >> 1], wb_ = cnt[bm >> 1];
+                const unsigned en = (b & 1u) ? wa_ >> 16 : wa_ & 0xFFFFu;
+                const unsigned sb_ = (b == 0u) ? 0u : ((bm & 1u) ? wb_ >> 16 : wb_ & 0xFFFFu);
+                const bool rsv = (bb >> 15) != 0u;
+                unsigned less = sb_, eq;
+                if (rsv) {
+                    eq = en - sb_;
+                } else {
+                    eq = 0u;
+                    const unsigned last = en - 1u;
+                    for (unsigned m2 = sb_; m2 <= last; m2 += 4u) {
+                        const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
+                        const double y0 = val[m2];
+                        const double y1 = val[i1 <= last ? i1 : last];
+                        const double y2 = val[i2 <= last ? i2 : last];
+                        const double y3 = val[i3 <= last ? i3 : last];
+                        less += (y0 < x) ? 1u : 0u;
+                        eq += (y0 == x) ? 1u : 0u;
+                        less += (i1 <= last && y1 < x) ? 1u : 0u;
+                        eq += (i1 <= last && y1 == x) ? 1u : 0u;
+                        less += (i2 <= last && y2 < x) ? 1u : 0u;
+                        eq += (i2 <= last && y2 == x) ? 1u : 0u;
+                        less += (i3 <= last && y3 < x) ? 1u : 0u;
+                        eq += (i3 <= last && y3 == x) ? 1u : 0u;
+                    }
+                }
+                const unsigned gl = g0 + less;
+                const unsigned r2 = 2u * gl + eq + 1u; // doubled tied rank: first + last place of the run of equals, 1-based
+                anyodd |= r2 & 1u;                      // (a tie group of even size has a half-integer rank: odd doubled value)
+                if (tin) {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+                        if (t < ntgt && tp[t] - gl < eq) { ostat[t] = x; orank[t] = r2; }
+                }
+                unsigned pos = gl;
+                if (eq != 1u) {
+                    if (rsv) pos += sl - sb_;
+                    else for (unsigned m2 = sb_; m2 < sl; ++m2) pos += (val[m2] == x) ? 1u : 0u;
+                }
+                if (need_ra) ra[tgv & 0xFFFFu] = (unsigned short)r2;
+                sv[pos] = x;
+                st[pos] = (tgv >> 16) & 0xFFu;
+            }
+        }
+        lds_fence();
+        WPROF(13);
+    }
+    anyodd = (__ballot(anyodd != 0u) != 0ull) ? 1u : 0u;
+    mem_fence();
+    // ---- order statistics -> median / quantiles, in T arithmetic like the reference (Statistics.median: a/2 + b/2; type-7
+    // quantile: a + g (b - a)); x <= q as a comparison of doubled ranks: q lies between the two captured neighbours a <= b, the
+    // largest order statistic <= q is a (q < b) or b (q == b); anything else leaves the decision to the comparisons on x
+    T medT = (T)0, qq[2] = {(T)0, (T)0};
+    int zq_ok = 0;
+    unsigned r2q[2] = {0u, 0u};
+    {
+        int t = 0;
+        if (need_med) {
+            const T a = (T)ostat[0], b = (T)ostat[1];
+            medT = (n & 1u) ? a : (T)(a / (T)2 + b / (T)2);
+            t = 2;
+        }
+        if (need_q) {
+            zq_ok = 1;
+            for (int i = 0; i < 2; ++i) {
+                const T a = (T)ostat[t + 2 * i], b = (T)ostat[t + 2 * i + 1];
+                const T g = (T)kp.q_g[i];
+                const bool fin = (a - a == (T)0) && (b - b == (T)0);
+                qq[i] = fin ? (T)(a + (T)(g * (T)(b - a))) : (T)((T)(((T)1 - g) * a) + (T)(g * b));
+                const int pick = (qq[i] >= a && qq[i] < b) ? 0 : ((qq[i] == b) ? 1 : -1);
+                if (pick < 0) zq_ok = 0;
+                else r2q[i] = orank[t + 2 * i + pick];
+            }
+        }
+    }
+    if (lane == 0) {
+        ws->anyodd = anyodd; ws->med = (double)medT; ws->qlo = (double)qq[0]; ws->qhi = (double)qq[1];
+        ws->zq_ok = zq_ok; ws->r2q[0] = r2q[0]; ws->r2q[1] = r2q[1];
+    }
+    lds_fence();
+    WPROF(5);
+}
+
+// ------------------------------------------------------------------ fold: rhat(kind = tail) as a merge of the sorted copy
+// The folded values |T(x - med)| of the sorted slice S are two monotone runs mirrored at the median, A[a] = fold(S[imed-1-a])
+// and B[b] = fold(S[imed+b]) (rounding is monotone); their pooled tied ranks (src/utils.jl:148-158, 169-193) are those of a
+// two-way merge.  Tile boundaries by merge-path searches (one lane per boundary, all at once), then per tile of FT outputs:
+// both pieces staged in LDS (the next tile's loads already in flight), a diagonal search and four merge steps per lane, scores
+// by merged position (consecutive table entries), exact fixed-point sums per split chain by LDS atomics.  Members with equals
+// are set aside and counted exactly afterwards.  Sets ws->fallback when it cannot serve the slice.
+WV_PHASE void ph_fold(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA double* fa = (WV_LA double*)(wb + OFF_FA);
+    WV_LA double* fb = (WV_LA double*)(wb + OFF_FB);
+    WV_LA unsigned char* sa = (WV_LA unsigned char*)(wb + OFF_SA);
+    WV_LA unsigned char* sb = (WV_LA unsigned char*)(wb + OFF_SB);
+    WV_LA long long* facc = (WV_LA long long*)(wb + OFF_FACC);
+    WV_LA unsigned long long* tor = (WV_LA unsigned long long*)(wb + OFF_TOR);
+    WV_LA unsigned long long* tand = tor + WV_MAXM;
+    WV_LA unsigned* tcnt = (WV_LA unsigned*)(wb + OFF_TCNT);
+    WV_LA unsigned* tln = tcnt + WV_MAXM;
+    WV_LA unsigned* tb = (WV_LA unsigned*)(wb + OFF_TB);
+    WV_LA double* tval = (WV_LA double*)(wb + OFF_TVAL);
+    WV_LA unsigned char* tsl = (WV_LA unsigned char*)(wb + OFF_TSL);
+    WV_LA double* mean_j = (WV_LA double*)(wb + OFF_MEAN);
+    WV_LA double* var_j = mean_j + WV_MAXM;
+    const WV_GA double* sv = (const WV_GA double*)rfl64(ws->sv);
+    const WV_GA unsigned* st = (const WV_GA unsigned*)rfl64(ws->st);
+    typedef xs_of<T> ZT_t;
+    const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab;
+    const unsigned n = (unsigned)kp.n, niter = (unsigned)kp.niter;
+    const int m = kp.m;
+    const WV_GA ZT_t* gzd = gz + (2u * n + 1u);
+    const double inf = __builtin_inf(), dn = (double)niter;
+    const Fx fx = Fx::make(kp.niter);
+    const T medT = (T)rfld(ws->med);
+    auto fold = [&](double x) -> double {
+        const T d = (T)((T)x - medT);
+        return (double)(d < (T)0 ? -d : d);
+    };
+    const unsigned h = (n - 1u) / 2u;
+    int zero = 0;
+    asm volatile("" : "+v"(zero));
+    const unsigned imed = rflu(((T)sv[h + zero] == medT) ? h : h + 1u);
+    bool ok;
+    {
+        const double below = sv[(imed > 0u ? imed - 1u : 0u) + zero], at = sv[(imed < n ? imed : n - 1u) + zero];
+        ok = (imed == 0u || (T)below <= medT) && (imed == n || (T)at >= medT); // (equals of the median may sit on either side)
+        const double f0 = fold(sv[zero]), f1 = fold(sv[n - 1u + zero]);
+        ok = ok && f0 < inf && f1 < inf; // (the +inf sentinels behind the runs must beat every member)
+        ok = rfl(ok ? 1 : 0) != 0;
+    }
+    const unsigned nA = imed, nB = n - imed;
+    const unsigned ntile = (n + (unsigned)FT - 1u) / (unsigned)FT;
+#pragma unroll
+    for (int q = 0; q < 2 * WV_MAXM * 8 / 64; ++q) facc[lane + 64 * q] = 0;
+    if (lane < WV_MAXM) { tor[lane] = 0ull; tand[lane] = ~0ull; tcnt[lane] = 0u; }
+    if (lane == 0) *tln = 0u;
+    if (ok) {
+        // tb[k] = members of A among the first k FT merged outputs (A first on ties): A[mid] is among the first d outputs iff
+        // A[mid] <= B[d - mid - 1], monotone in mid
+        if ((unsigned)lane <= ntile) {
+            const unsigned d = ((unsigned)lane * (unsigned)FT < n) ? (unsigned)lane * (unsigned)FT : n;
+            unsigned lo = d > nB ? d - nB : 0u, hi = d < nA ? d : nA;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                if (fold(sv[imed - 1u - mid]) <= fold(sv[imed + (d - mid - 1u)])) lo = mid + 1u; else hi = mid;
+            }
+            tb[lane] = lo;
+        }
+        lds_fence();
+        const unsigned cp = (unsigned)lane & 7u;
+        // a tile's pieces: entry e = member e - 1 of the piece (the member in front of it, its na / nb members, the one behind)
+        double xa[5], xb[5];
+        unsigned la[5], lb[5];
+        auto issue = [&](unsigned k) {
+            const unsigned a0 = rflu(tb[k]), b0 = k * (unsigned)FT - a0;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = 64 * i + lane;
+                const long long ia = (long long)a0 + e - 1, ib = (long long)b0 + e - 1;
+                const bool va = e < FE && ia >= 0 && ia < (long long)nA, vb = e < FE && ib >= 0 && ib < (long long)nB;
+                const unsigned srcA = va ? (unsigned)((long long)imed - 1 - ia) : 0u;
+                const unsigned srcB = vb ? (unsigned)((long long)imed + ib) : 0u;
+                xa[i] = sv[srcA]; la[i] = st[srcA];
+                xb[i] = sv[srcB]; lb[i] = st[srcB];
+            }
+        };
+        issue(0u);
+        for (unsigned k = 0; k < ntile; ++k) {
+            const unsigned k0 = k * (unsigned)FT;
+            const unsigned cntk = (n - k0 < (unsigned)FT) ? n - k0 : (unsigned)FT;
+            const unsigned a0 = rflu(tb[k]), a1 = rflu(tb[k + 1u]), b0 = k0 - a0;
+            const unsigned na = a1 - a0, nb = cntk - na;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int e = 64 * i + lane;
+                if (e < FE) {
+                    const long long ia = (long long)a0 + e - 1, ib = (long long)b0 + e - 1;
+                    const bool va = ia >= 0 && ia < (long long)nA, vb = ib >= 0 && ib < (long long)nB;
+                    fa[e] = va ? fold(xa[i]) : (e == 0 ? -inf : inf);
+                    fb[e] = vb ? fold(xb[i]) : (e == 0 ? -inf : inf);
+                    sa[e] = (unsigned char)la[i];
+                    sb[e] = (unsigned char)lb[i];
+                }
+            }
+            // the scores of this lane's four merged positions: position p has rank p + 1 unless it has equals
+            const unsigned d = 4u * (unsigned)lane;
+            double zq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { const unsigned pp = k0 + d + (unsigned)i; zq[i] = (double)gzd[(pp < n ? pp : n - 1u) + 1u]; }
+            if (k + 1u < ntile) issue(k + 1u);
+            lds_fence();
+            if (d < cntk) {
+                // diagonal: members of the A piece among the first d outputs of the tile
+                unsigned lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
+                while (lo < hi) {
+                    const unsigned mid = (lo + hi) >> 1;
+                    if (fa[1u + mid] <= fb[d - mid]) lo = mid + 1u; else hi = mid;
+                }
+                unsigned a = lo, b = d - lo;
+                const double pa = fa[a], pb = fb[b];
+                double prev = pa > pb ? pa : pb;
+                double ca = fa[1u + a], cb = fb[1u + b];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool ta = ca <= cb;
+                    const double cur = ta ? ca : cb;
+                    const unsigned slot = ta ? (unsigned)sa[1u + a] : (unsigned)sb[1u + b];
+                    a += ta ? 1u : 0u;
+                    b += ta ? 0u : 1u;
+                    const double nx = ta ? fa[1u + a] : fb[1u + b];
+                    ca = ta ? nx : ca;
+                    cb = ta ? cb : nx;
+                    const double nxt = ca < cb ? ca : cb;
+                    if (d + (unsigned)i < cntk) {
+                        if (cur == prev || cur == nxt) { // equals exist: exact count after the tiles
+                            const unsigned ti = lds_add(tln, 1u);
+                            if (ti < (unsigned)WTCAP) { tval[ti] = cur; tsl[ti] = (unsigned char)slot; }
+                        } else if (slot < (unsigned)m) {
+                            const double zv = zq[i];
+                            lds_add((WV_LA unsigned long long*)&facc[slot * 8u + cp], (unsigned long long)fx.u(zv));
+                            lds_add((WV_LA unsigned long long*)&facc[WV_MAXM * 8 + slot * 8u + cp], (unsigned long long)fx.uu(zv * zv));
+                        }
+                    }
+                    prev = cur;
+                }
+            }
+            lds_fence(); // (the next tile's staging stores come after every read of this tile's image)
+        }
+    }
+    unsigned nt = 0u;
+    if (ok) { nt = rflu(*tln); if (nt > (unsigned)WTCAP) ok = false; }
+    if (!ok) nt = 0u;
+    // members with equals: exact tied rank from both runs (binary searches in the sorted copy)
+    if ((unsigned)lane < nt) {
+        auto count_run = [&](double f, bool arun, bool le) -> unsigned {
+            unsigned lo = 0u, hi = arun ? nA : nB;
+            while (lo < hi) {
+                const unsigned mid = (lo + hi) >> 1;
+                const double x = fold(arun ? sv[imed - 1u - mid] : sv[imed + mid]);
+                if (le ? (x <= f) : (x < f)) lo = mid + 1u; else hi = mid;
+            }
+            return lo;
+        };
+        const unsigned cp = (unsigned)lane & 7u;
+        const double cur = tval[lane];
+        const unsigned slot = tsl[lane];
+        const unsigned lA = count_run(cur, true, false), lB = count_run(cur, false, false);
+        const unsigned eA = count_run(cur, true, true), eB = count_run(cur, false, true);
+        const unsigned less = lA + lB, eq = (eA - lA) + (eB - lB);
+        const double zv = (double)gz[2u * less + eq + 1u];
+        if (slot < (unsigned)m) {
+            lds_add((WV_LA unsigned long long*)&facc[slot * 8u + cp], (unsigned long long)fx.u(zv));
+            lds_add((WV_LA unsigned long long*)&facc[WV_MAXM * 8 + slot * 8u + cp], (unsigned long long)fx.uu(zv * zv));
+            const unsigned long long zb = (unsigned long long)__double_as_longlong(zv);
+            lds_or(&tor[slot], zb);
+            lds_and(&tand[slot], zb);
+            lds_add(&tcnt[slot], 1u);
+        }
+    }
+    lds_fence();
+    if (lane < m) { // sums -> moments: the expressions of fold_merge_phase (mdt_fold.inc)
+        long long s1 = 0, s2 = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s1 += facc[lane * 8 + c]; s2 += facc[WV_MAXM * 8 + lane * 8 + c]; }
+        const double S1 = (double)s1 * fx.i1, S2 = (double)s2 * fx.i2;
+        const double mu = S1 / dn;
+        const bool constant = niter == 1u || (tcnt[lane] == niter && tor[lane] == tand[lane]);
+        mean_j[lane] = mu;
+        var_j[lane] = constant ? 0.0 : (S2 - mu * S1) / (dn - 1.0);
+    }
+    lds_fence();
+    const double rt = combine_moments(mean_j, var_j, m, kp.cf).rhat;
+    if (lane == 0) { ws->out[3] = rt; if (!ok) ws->fallback = 1; }
+    lds_fence();
+    WPROF(6);
+}
+
+// ------------------------------------------------------------------ bulk series: moments, lag products, Geyer's scan
+// Per split chain: doubled ranks (time order) -> scores (the workgroup's LDS table) -> stage in LDS, shifted by the score of
+// the chain's first draw; exact fixed-point moments (the integers and expressions of series_z_phase, mdt_series.inc: R-hat is
+// the same bits); centred; lag products (src/ess_rhat.jl:170-178) as blocked Hankel tiles on v_mfma_f64_16x16x4_f64,
+// accumulated over the chains; Geyer's initial monotone sequence (:555-594) between blocks of 32 lags.  While a chain is
+// staged its tail-ESS indicator words are taken from the ranks (x <= q <=> doubled rank <= r2q).
+WV_PHASE void ph_series(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA double* lagA = (WV_LA double*)(wb + OFF_LAGA);
+    WV_LA double* mean_j = (WV_LA double*)(wb + OFF_MEAN);
+    WV_LA double* var_j = mean_j + WV_MAXM;
+    WV_LA double* mu_j = var_j + WV_MAXM;
+    WV_LA double* stage = (WV_LA double*)(wb + OFF_STG);
+    typedef xs_of<T> ZT_t;
+    const WV_LA ZT_t* lz = (const WV_LA ZT_t*)(unsigned long long)rflu(ws->lz);
+    const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab;
+    const WV_GA unsigned short* ra = (const WV_GA unsigned short*)rfl64(ws->ra);
+    const unsigned D = (unsigned)kp.D;
+    const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
+    const int m = kp.m;
+    const long long maxlag = kp.maxlag;
+    const double nan = __builtin_nan(""), dn = (double)niter, dm = (double)m;
+    const Fx fx = Fx::make(kp.niter);
+    const bool acov = kp.need_eb && kp.ess_ok;
+    const bool anyodd = rflu(ws->anyodd) != 0u;
+    const unsigned nblk = (niter + 63u) >> 6;
+    const int c_hi = 16 * ((int)maxlag / 16 + 1);
+    auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); };
+    // indicator words behind the stage, when both fit the view
+    const int nwS = (int)nblk, nwU = nwS + (int)(maxlag >> 6) + 2;
+    const unsigned stg_doubles = 64u * nblk + 272u;
+    const bool bits = kp.need_et && kp.ess_ok && rfl(ws->zq_ok) != 0 && (int)(stg_doubles * 8u) + 2 * m * nwU * 8 <= VIEW_BYTES;
+    WV_LA unsigned long long* sb2 = (WV_LA unsigned long long*)(stage + stg_doubles);
+    const unsigned r2q0 = rflu(ws->r2q[0]), r2q1 = rflu(ws->r2q[1]);
+    if (bits) { for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull; }
+    for (int k = lane; k < 256; k += 64) lagA[k] = 0.0;
+    WB wbm = {0.0, 0.0, 0.0};
+    double eb_ = nan;
+    double pt = 0.0, gsum = 0.0; // Geyer's state, every lane the same
+    long long gk = 0;
+    bool started = false, done = false;
+    long long k0 = 0;
+    int block = 0;
+    constexpr int NB = (WV_NITER + 63) / 64;
+    unsigned rn[NB];
+    auto issue = [&](int j) { // the ranks of split chain j: all its rows in flight
+        const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
+        const WV_GA unsigned short* rj = ra + (c * D + row0(k));
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+            rn[b] = rj[t < niter ? t : niter - 1u];
+        }
+    };
+    while (true) {
+        long long kend = k0 + 16 * (ZT - 1);
+        if (kend > maxlag + 1) kend = maxlag + 1;
+        int cb[ZT];
+#pragma unroll
+        for (int i = 0; i < ZT; ++i) { const int c = (int)k0 + 16 * i; cb[i] = c < c_hi ? c : c_hi; }
+        for (unsigned t = 64u * nblk + (unsigned)lane; t < stg_doubles; t += 64u) stage[t] = 0.0; // zeros behind every chain
+        d4 acc[ZT];
+#pragma unroll
+        for (int i = 0; i < ZT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+        issue(0);
+        for (int j = 0; j < m; ++j) {
+            unsigned r2[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) r2[b] = rn[b];
+            if (j + 1 < m) issue(j + 1);
+            double K = 0.0;
+            long long a1 = 0, a2 = 0;
+            const double mu0 = (block > 0) ? mu_j[j] : 0.0;
+            double z[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) z[b] = (double)lz[r2[b] >> 1];
+            if (anyodd) { // a half-integer rank: the table by doubled rank
+#pragma unroll
+                for (int b = 0; b < NB; ++b) if (r2[b] & 1u) z[b] = (double)gz[r2[b]];
+            }
+            K = readlane_d(z[0], 0);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                if ((unsigned)b < nblk) {
+                    const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                    const bool okt = t < niter;
+                    const double u = okt ? z[b] - K : 0.0;
+                    if (block == 0) {
+                        a1 += okt ? fx.u(u) : 0;
+                        a2 += okt ? fx.uu(u * u) : 0;
+                        stage[t] = u;
+                        if (bits) {
+                            const unsigned long long q0 = __ballot(okt && r2[b] <= r2q0), q1 = __ballot(okt && r2[b] <= r2q1);
+                            if (lane == 0) { sb2[(2 * j) * nwU + b] = q0; sb2[(2 * j + 1) * nwU + b] = q1; }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                    } else {
+                        stage[t] = okt ? u - mu0 : 0.0;
+                    }
+                }
+            }
+            if (block == 0) {
+                const double S1 = (double)wave_sum_i64(a1) * fx.i1, S2 = (double)wave_sum_i64(a2) * fx.i2;
+                const double mu = S1 / dn;
+                const double Cc = S2 - mu * S1;
+                if (lane == 0) { var_j[j] = Cc / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
+                if (acov) {
+                    lds_fence();
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                        if ((unsigned)b < nblk && t < niter) stage[t] -= mu;
+                    }
+                }
+            }
+            WPROF(14);
+            if (acov) {
+                lds_fence();
+                // A = u[64 b + lane], B = the same 64 values shifted by the tile's base: lag c + j - i sits at (i, j) of tile c
+                for (unsigned b = 0; b < nblk; ++b) {
+                    const WV_LA double* pb = stage + 64u * b + (unsigned)lane;
+                    const double a = pb[0];
+#pragma unroll
+                    for (int i = 0; i < ZT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[cb[i]], acc[i], 0, 0, 0);
+                }
+            }
+            lds_fence();
+            WPROF(15);
+        }
+        if (block == 0) wbm = combine_moments(mean_j, var_j, m, kp.cf);
+        if (!acov) break;
+        { // the diagonals of the tiles: lane e holds strip lag e - 15 (relative to k0)
+            double sdiag = 0.0;
+            WV_LA double* stg = stage;
+#pragma unroll
+            for (int i = 0; i < ZT; ++i) {
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) stg[((lane >> 4) + 4 * rg) * 17 + (lane & 15)] = acc[i][rg];
+                lds_fence();
+                const int dd = lane - 16 * i;
+                if (dd >= 0 && dd <= 30) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int jj = r + dd - 15;
+                        if (jj >= 0 && jj < 16) sdiag += stg[r * 17 + jj];
+                    }
+                }
+                lds_fence();
+            }
+            const long long kq = k0 + lane - 15;
+            if (lane >= 15 && kq < kend) lagA[kq] = sdiag;
+            lds_fence();
+        }
+        { // Geyer's initial monotone sequence over the lags available so far (the logic of series_combine)
+            const double W = wbm.W, inv_varp = 1.0 / wbm.varp;
+            auto rho = [&](long long k) -> double {
+                const double ma = lagA[k] / dm / dn;
+                return 1.0 - inv_varp * (W - ma);
+            };
+            const long long avail = kend - 1;
+            if (!started) { pt = 1.0 + rho(1); gsum = pt; gk = 2; started = true; }
+            int stop = 0;
+            while (gk < maxlag - 1) {
+                if (gk + 1 > avail) break;
+                const double delta = rho(gk) + rho(gk + 1);
+                if (!(delta > 0.0)) { stop = 1; break; }
+                pt = jl_min(delta, pt);
+                gsum += pt;
+                gk += 2;
+            }
+            if (!(gk < maxlag - 1)) stop = 1;
+            if (stop && (gk <= avail || !(maxlag > 1))) {
+                const double rho_even = (maxlag > 1) ? rho(gk) : 0.0;
+                const double tau = jl_max(0.0, 2.0 * gsum + jl_max(0.0, rho_even) - 1.0);
+                double e = jl_min(1.0 / tau, kp.rel_ess_max);
+                if (!kp.relative) e *= kp.ntotal;
+                eb_ = e;
+                done = true;
+            }
+        }
+        if (rfl(done ? 1 : 0)) break;
+        k0 = kend;
+        ++block;
+    }
+    if (acov && kp.method == 1) { // FFTAutocovMethod normalises by the chain's own lag 0: 0/0 = NaN for a constant split chain (src/ess_rhat.jl:192)
+        bool anyc = false;
+        for (int j = 0; j < m; ++j) anyc = anyc || (var_j[j] == 0.0);
+        if (anyc) eb_ = nan;
+    }
+    if (lane == 0) { ws->out[0] = acov ? eb_ : nan; ws->out[1] = wbm.rhat; ws->bits_done = bits ? 1 : 0; }
+    lds_fence();
+    WPROF(7);
+}
+
+// ------------------------------------------------------------------ tail ESS: indicators of x <= q (src/ess_rhat.jl:301-311, 647-659)
+// The indicator words of every split chain (from the ranks while the chain was staged, else built here from the ranks or from
+// x itself), per chain and lag sum I_t I_{t+k} = popcount(bits & bits >> k), centred exactly in int64, lanes = 16 lags x 4
+// word segments; lanes 0 / 1 run Geyer's scan of the two indicators between blocks of 16 lags.
+WV_PHASE void ph_indicators(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    WV_LA double* icov = (WV_LA double*)(wb + OFF_ICOV);
+    WV_LA double* imean = (WV_LA double*)(wb + OFF_IMEAN);
+    const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
+    const WV_GA unsigned short* ra = (const WV_GA unsigned short*)rfl64(ws->ra);
+    const unsigned D = (unsigned)kp.D;
+    const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
+    const int m = kp.m;
+    const long long cs = kp.cstride, maxlag = kp.maxlag;
+    const double nan = __builtin_nan(""), dn = (double)niter, dm = (double)m;
+    auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); };
+    const int nwS = (int)((niter + 63u) >> 6);
+    const int nwU = nwS + (int)(maxlag >> 6) + 2;
+    const bool have = rfl(ws->bits_done) != 0;
+    const unsigned stg_doubles = 64u * (unsigned)nwS + 272u;
+    WV_LA unsigned long long* sb2 = (WV_LA unsigned long long*)(wb + OFF_SB2);
+    if (have) { // the words the series phase took sit behind its stage, where this phase's tables go: move them (through registers)
+        const WV_LA unsigned long long* src = (const WV_LA unsigned long long*)((WV_LA double*)(wb + OFF_STG) + stg_doubles);
+        constexpr int NWL = (2 * WV_MAXM * NWU_MAX + 63) / 64;
+        unsigned long long tmp[NWL];
+#pragma unroll
+        for (int q = 0; q < NWL; ++q) { const int i = lane + 64 * q; tmp[q] = (i < 2 * m * nwU) ? src[i] : 0ull; }
+        lds_fence();
+#pragma unroll
+        for (int q = 0; q < NWL; ++q) { const int i = lane + 64 * q; if (i < 2 * m * nwU) sb2[i] = tmp[q]; }
+        lds_fence();
+    } else {
+        const bool byrank = rfl(ws->zq_ok) != 0;
+        const unsigned r2q0 = rflu(ws->r2q[0]), r2q1 = rflu(ws->r2q[1]);
+        const T qloT = (T)rfld(ws->qlo), qhiT = (T)rfld(ws->qhi);
+        for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull;
+        lds_fence();
+        constexpr int NB = (WV_NITER + 63) / 64;
+        for (int j = 0; j < m; ++j) {
+            const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
+            unsigned long long q0[NB], q1[NB];
+            if (byrank) {
+                const WV_GA unsigned short* rj = ra + (c * D + row0(k));
+                unsigned r2[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rj[t < niter ? t : niter - 1u]; }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
+                    q0[b] = __ballot(okt && r2[b] <= r2q0);
+                    q1[b] = __ballot(okt && r2[b] <= r2q1);
+                }
+            } else {
+                const WV_GA T* xr = xp + (long long)c * cs + row0(k);
+                T xv[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; xv[b] = xr[t < niter ? t : niter - 1u]; }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
+                    q0[b] = __ballot(okt && xv[b] <= qloT);
+                    q1[b] = __ballot(okt && xv[b] <= qhiT);
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) if (b < nwS) { sb2[(2 * j) * nwU + b] = q0[b]; sb2[(2 * j + 1) * nwU + b] = q1[b]; }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    for (int i = lane; i < 2 * 256; i += 64) icov[i] = 0.0;
+    lds_fence();
+    double ipt = 0.0, isum = 0.0, iess = nan;
+    long long ik = 0;
+    bool istarted = false, idone = lane >= 2;
+    const int kl = lane & 15, seg = lane >> 4;
+    const int wq = (nwS + 3) >> 2, i0 = seg * wq, i1 = (i0 + wq < nwS) ? i0 + wq : nwS;
+    long long k0 = 0;
+    while (true) {
+        long long kend = k0 + 16;
+        if (kend > maxlag + 1) kend = maxlag + 1;
+        const long long k = k0 + kl;
+        double cov0 = 0.0, cov1 = 0.0;
+        for (int u = 0; u < 2 * m; ++u) {
+            const WV_LA unsigned long long* sbu = sb2 + u * nwU;
+            int sxp = 0, akp = 0;
+            if (k < kend) {
+                const int q = (int)(k >> 6), r = (int)(k & 63);
+                unsigned long long lo = sbu[i0 + q];
+                for (int i = i0; i < i1; ++i) {
+                    const unsigned long long v = sbu[i];
+                    const unsigned long long hi = sbu[i + q + 1];
+                    const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
+                    sxp += __popcll(v);
+                    akp += __popcll(v & vs);
+                    lo = hi;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            sxp += __shfl_xor(sxp, 16); sxp += __shfl_xor(sxp, 32);
+            akp += __shfl_xor(akp, 16); akp += __shfl_xor(akp, 32);
+            if (k < kend && seg == 0) {
+                const long long Sx = sxp, Ak = akp, ni = (long long)niter;
+                const int q = (int)(k >> 6);
+                long long head = 0, tail = 0; // ones among the first k / the last k positions
+                for (int i = 0; i <= q; ++i) {
+                    const long long nb2 = k - ((long long)i << 6);
+                    const unsigned long long mk = nb2 >= 64 ? ~0ull : (nb2 <= 0 ? 0ull : ((1ull << nb2) - 1ull));
+                    head += __popcll(sbu[i] & mk);
+                }
+                {
+                    const long long p0 = ni - k;
+                    for (int i = (int)((p0 > 0 ? p0 : 0) >> 6); i < nwS; ++i) {
+                        const long long bpos = (long long)i << 6;
+                        const long long sk = p0 - bpos;
+                        const unsigned long long mk = sk <= 0 ? ~0ull : (sk >= 64 ? 0ull : ~((1ull << sk) - 1ull));
+                        tail += __popcll(sbu[i] & mk);
+                    }
+                }
+                const long long Tk = Sx - head, Hk = Sx - tail;
+                const long long N = ni * ni * Ak - ni * Sx * (Hk + Tk) + (ni - k) * Sx * Sx;
+                double ck = (double)N / (dn * dn);
+                // FFTAutocovMethod normalises by the lag-0 value of the same chain: 0/0 -> NaN for a constant split chain (src/ess_rhat.jl:192)
+                if (kp.method == 1 && k > 0 && (Sx == 0 || Sx == ni)) ck = nan;
+                if (k == 0) imean[(u & 1) * WV_MAXM + (u >> 1)] = (double)Sx / dn;
+                cov0 += (u & 1) ? 0.0 : ck;
+                cov1 += (u & 1) ? ck : 0.0;
+            }
+            __builtin_amdgcn_wave_barrier(); // (every lane joins before the next unit's shuffles)
+        }
+        if (k < kend && seg == 0) { icov[k] = cov0; icov[256 + k] = cov1; }
+        lds_fence();
+        if (!idone) {
+            const int ind = lane;
+            const WV_LA double* cv = icov + ind * 256;
+            const double W = cv[0] / dm / (double)(niter - 1u);
+            double mb = 0.0;
+            for (int j = 0; j < m; ++j) mb += imean[ind * WV_MAXM + j];
+            mb /= dm;
+            double vb = 0.0;
+            for (int j = 0; j < m; ++j) { const double dd = imean[ind * WV_MAXM + j] - mb; vb = fma(dd, dd, vb); }
+            vb /= (double)(m > 1 ? m - 1 : m);
+            const double varp = kp.cf * W + vb;
+            const double inv_varp = 1.0 / varp;
+            auto rho = [&](long long kk) -> double {
+                const double ma = cv[kk] / dm / dn;
+                return 1.0 - inv_varp * (W - ma);
+            };
+            const long long avail = kend - 1;
+            if (!istarted) { ipt = 1.0 + rho(1); isum = ipt; ik = 2; istarted = true; }
+            int stop = 0;
+            while (ik < maxlag - 1) {
+                if (ik + 1 > avail) break;
+                const double delta = rho(ik) + rho(ik + 1);
+                if (!(delta > 0.0)) { stop = 1; break; }
+                ipt = jl_min(delta, ipt);
+                isum += ipt;
+                ik += 2;
+            }
+            if (!(ik < maxlag - 1)) stop = 1;
+            if (stop && (ik <= avail || !(maxlag > 1))) {
+                const double rho_even = (maxlag > 1) ? rho(ik) : 0.0;
+                const double tau = jl_max(0.0, 2.0 * isum + jl_max(0.0, rho_even) - 1.0);
+                double e = jl_min(1.0 / tau, kp.rel_ess_max);
+                if (!kp.relative) e *= kp.ntotal;
+                iess = e;
+                idone = true;
+            }
+        }
+        if (__ballot(!idone) == 0ull) break;
+        k0 = kend;
+    }
+    const double et = jl_min(readlane_d(iess, 0), readlane_d(iess, 1));
+    if (lane == 0) ws->out[2] = et;
+    lds_fence();
+    WPROF(8);
+}
 
 // ------------------------------------------------------------------ the kernel
+#define WDBG(code) do { if (wa.dbg && lane == 0) __hip_atomic_store(wa.dbg + gw, (unsigned)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ kpp, WvArgs wa) {
     const WV_CA KP& kp = *(const WV_CA KP*)(unsigned long long)kpp;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef xs_of<T> ZT_t;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const unsigned n = (unsigned)kp.n, D = (unsigned)kp.D, C = (unsigned)kp.C;
-    const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
-    const int m = kp.m;
-    const long long cs = kp.cstride, ps = kp.pstride;
-    const double inf = __builtin_inf(), nan = __builtin_nan("");
-
-    const unsigned gw = blockIdx.x * (blockDim.x >> 6) + (unsigned)(threadIdx.x >> 6);
+    const unsigned n = (unsigned)kp.n;
+    const unsigned gw = blockIdx.x * (blockDim.x >> 6) + (unsigned)w;
+    const double nan = __builtin_nan("");
     WDBG(1);
     // ---- the normal-score table of whole ranks, once per workgroup: lz[r] = Phi^-1((r - 3/8) / (n + 1/4)), r = 1 .. n
-    ZT_t* lz = (ZT_t*)smem;
-    const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab; // by doubled rank [0, 2n], then the dense copy for whole ranks
-    const WV_GA ZT_t* gzd = gz + (2u * n + 1u);
-    for (unsigned i = (unsigned)tid; i <= n; i += blockDim.x) lz[i] = gzd[i];
+    {
+        ZT_t* lz = (ZT_t*)smem;
+        const WV_GA ZT_t* gzd = (const WV_GA ZT_t*)kp.ztab + (2u * n + 1u); // (behind the table by doubled rank: the dense copy for whole ranks)
+        for (unsigned i = (unsigned)tid; i <= n; i += blockDim.x) lz[i] = gzd[i];
+    }
     __syncthreads(); // the only workgroup barrier of the launch
     WDBG(2);
-
-    unsigned char* wb = smem + wa.tab_bytes + w * PERWAVE;
-    double* sp = (double*)(wb + OFF_SP);
-    double* iw = (double*)(wb + OFF_IW);
-    double* lagA = (double*)(wb + OFF_LAGA);
-    unsigned* ccur = (unsigned*)(wb + OFF_CCUR);
-    unsigned short* rtab = (unsigned short*)(wb + OFF_RTAB);
-    double* ostat = (double*)(wb + OFF_OST);
-    double* mean_j = (double*)(wb + OFF_MEAN);
-    double* var_j = mean_j + WV_MAXM;
-    double* mu_j = var_j + WV_MAXM;
-    unsigned char* clsb = (unsigned char*)(wb + OFF_VAL);
-    double* val = (double*)(wb + OFF_VAL);
-    unsigned* tagl = (unsigned*)(wb + OFF_TAG);
-    unsigned short* binid = (unsigned short*)(wb + OFF_BIN);
-    unsigned* cnt = (unsigned*)(wb + OFF_CNT);
-    double* fa = (double*)(wb + OFF_FA);
-    double* fb = (double*)(wb + OFF_FB);
-    unsigned char* sa = (unsigned char*)(wb + OFF_SA);
-    unsigned char* sb = (unsigned char*)(wb + OFF_SB);
-    long long* facc = (long long*)(wb + OFF_FACC);
-    unsigned long long* tor = (unsigned long long*)(wb + OFF_TOR);
-    unsigned long long* tand = tor + WV_MAXM;
-    unsigned* tcnt = (unsigned*)(wb + OFF_TCNT);
-    unsigned* tln = tcnt + WV_MAXM;
-    double* tval = (double*)(wb + OFF_TVAL);
-    unsigned char* tsl = (unsigned char*)(wb + OFF_TSL);
-    double* stage = (double*)(wb + OFF_STG);
-    unsigned long long* sb2 = (unsigned long long*)(wb + OFF_SB2);
-    double* icov = (double*)(wb + OFF_ICOV);
-    double* imean = (double*)(wb + OFF_IMEAN);
-
-    WV_GA double* sv = (WV_GA double*)(wa.sv + (long long)gw * wa.npad);
-    WV_GA unsigned* st = (WV_GA unsigned*)(wa.st + (long long)gw * wa.npad);
-    WV_GA unsigned short* ra = (WV_GA unsigned short*)(wa.ra + (long long)gw * wa.npad);
-
-    const bool need_bulk = kp.need_eb || kp.need_rb;
-    const bool need_med = kp.need_rt != 0;
-    const bool need_q = kp.need_et && kp.ess_ok;
-    const Fx fx = Fx::make(kp.niter);
-    const double dn = (double)niter, dm = (double)m;
-    const long long maxlag = kp.maxlag;
-    auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); }; // src/utils.jl:29-36
+    const unsigned smem0 = (unsigned)(unsigned long long)(WV_LA unsigned char*)smem;
+    const unsigned wbase = rflu(smem0 + (unsigned)wa.tab_bytes + (unsigned)w * (unsigned)PERWAVE);
+    WV_LA unsigned char* wb = (WV_LA unsigned char*)(unsigned long long)wbase;
+    WV_LA WS* ws = (WV_LA WS*)(wb + OFF_WS);
+    if (lane == 0) {
+        ws->kp = (unsigned long long)kpp;
+        ws->sv = (unsigned long long)(wa.sv + (long long)gw * wa.npad);
+        ws->st = (unsigned long long)(wa.st + (long long)gw * wa.npad);
+        ws->ra = (unsigned long long)(wa.ra + (long long)gw * wa.npad);
+        ws->dbg = (unsigned long long)wa.dbg;
+        ws->lz = smem0;
+        ws->gw = gw;
+        ws->stop = wa.stop;
+    }
+#ifdef WV_PROF
+    if (lane < 16) ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane] = 0ull;
+    if (lane == 0) ((WV_LA unsigned long long*)(wb + OFF_PROF))[16] = (unsigned long long)__builtin_readcyclecounter();
+#endif
+    lds_fence();
 
     while (true) {
-        WDBG(72);
         int tk = 0;
         if (lane == 0) tk = atomicAdd(kp.status + 1, 1);
-        WDBG(73);
         tk = rfl(tk);
         WDBG(0x100 + tk);
         if (tk >= kp.P) break;
         const long long p = tk;
-        const WV_GA T* xp = (const WV_GA T*)kp.x + p * ps;
-        bool fallback = false; // (scalar: set from ballots and scalar values only)
-        bool skip = false;     // diagnostics: the remaining phases are skipped, the outputs stay NaN
-
-        // ================================================================ sample -> splitters
-        {
-            double a, b;
-            {
-                const unsigned i0 = (unsigned)lane, i1 = 64u + (unsigned)lane;
-                const unsigned q0 = ((2u * i0 + 1u) * n) >> 8, q1 = ((2u * i1 + 1u) * n) >> 8;
-                const unsigned c0 = q0 / D, c1 = q1 / D;
-                a = (double)xp[(long long)c0 * cs + (q0 - c0 * D)];
-                b = (double)xp[(long long)c1 * cs + (q1 - c1 * D)];
-                a = (a - a == 0.0) ? a : inf;
-                b = (b - b == 0.0) ? b : inf;
-            }
-            WDBG(4);
-            for (int k = 2; k <= 64; k <<= 1) {
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    const bool lower = (lane & j) == 0;
-                    const bool upa = (k == 64) ? true : ((lane & k) == 0);
-                    const bool upb = (k == 64) ? false : ((lane & k) == 0);
-                    const double oa = __shfl_xor(a, j), ob = __shfl_xor(b, j);
-                    a = (lower == upa) ? (oa < a ? oa : a) : (oa > a ? oa : a);
-                    b = (lower == upb) ? (ob < b ? ob : b) : (ob > b ? ob : b);
-                }
-            }
-            { const double lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; }
-            for (int j = 32; j > 0; j >>= 1) {
-                const bool lower = (lane & j) == 0;
-                const double oa = __shfl_xor(a, j), ob = __shfl_xor(b, j);
-                a = lower ? (oa < a ? oa : a) : (oa > a ? oa : a);
-                b = lower ? (ob < b ? ob : b) : (ob > b ? ob : b);
-            }
-            WDBG(5);
-            sp[1 + lane] = a;
-            sp[65 + lane] = (lane == 63) ? inf : b; // 127 splitters; the sentinel ends the search
-            ccur[lane] = 0u;
-            ccur[64 + lane] = 0u;
-            lds_fence();
-            // inverse widths of the inner classes c = 1 .. 126: [sp[c], sp[c + 1])
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int c = lane + 64 * q;
-                if (c >= 1 && c <= 126) {
-                    const double wd = sp[c + 1] - sp[c];
-                    double v = (wd > 0.0 && wd < inf) ? 1.0 / wd : 0.0;
-                    if (!(v < inf)) v = 0.0;
-                    iw[c] = v;
-                }
-            }
+        if (lane == 0) {
+            ws->p = p;
+            ws->xp = (unsigned long long)((const T*)kp.x + p * kp.pstride);
+            ws->fallback = 0; ws->zq_ok = 0; ws->bits_done = 0; ws->anyodd = 0u; ws->nrounds = 0u;
+            ws->out[0] = nan; ws->out[1] = nan; ws->out[2] = nan; ws->out[3] = nan;
         }
-
+        lds_fence();
+        WPROF(0);
+        const int stop = wa.stop; // diagnostics: the parameter ends after phase `stop`, its outputs stay NaN
         WDBG(10);
-        if (wa.stop == 1) skip = true;
-        // ================================================================ pass A: classes, histogram, range
-        double xmin = inf, xmax = -inf;
-        if (!skip) {
-            unsigned bad = 0u;
-            for (unsigned c = 0; c < C; ++c) {
-                const WV_GA T* xc = xp + (long long)c * cs;
-                const unsigned eb = c * D;
-                for (unsigned d0 = 0; d0 < D; d0 += 256u) {
-                    double v[4];
-                    unsigned pos[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned d = d0 + 64u * u + (unsigned)lane;
-                        v[u] = (double)xc[d < D ? d : D - 1u];
-                        pos[u] = 0u;
-                    }
-#pragma unroll
-                    for (unsigned step = 64u; step > 0u; step >>= 1) {
-                        double t[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) t[u] = sp[pos[u] + step];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) pos[u] += (t[u] <= v[u]) ? step : 0u;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const unsigned d = d0 + 64u * u + (unsigned)lane;
-                        if (d < D) {
-                            bad |= (v[u] - v[u] == 0.0) ? 0u : 1u;
-                            xmin = v[u] < xmin ? v[u] : xmin;
-                            xmax = v[u] > xmax ? v[u] : xmax;
-                            atomicAdd(&ccur[pos[u]], 1u);
-                            clsb[eb + d] = (unsigned char)pos[u];
-                        }
-                    }
-                }
-            }
-            fallback = __ballot(bad != 0u) != 0ull;
-        }
-        unsigned nrounds = 0u;
-        if (!fallback && !skip) {
-            xmin = wave_min_d(xmin);
-            xmax = wave_max_d(xmax);
-            lds_fence();
-            const unsigned h0 = ccur[2 * lane], h1 = ccur[2 * lane + 1];
-            const unsigned tot = h0 + h1, incl = wave_incl_scan_u32(tot);
-            const unsigned b0 = incl - tot, b1 = b0 + h0;
-            const unsigned cmax = rflu(wave_max_u32(h0 > h1 ? h0 : h1)); // (scalar: every branch on it is a scalar branch)
-            if (cmax >= (unsigned)WR) fallback = true; // a point mass (or a crowd) larger than a round
-            else {
-                const unsigned Q = (unsigned)WR - cmax;
-                const unsigned r0 = b0 / Q, r1 = b1 / Q;
-                unsigned rprev = (unsigned)__shfl_up((int)r1, 1);
-                const unsigned f0 = (lane == 0 || r0 != rprev) ? 1u : 0u, f1 = (r1 != r0) ? 1u : 0u;
-                const unsigned nb = f0 + f1, kin = wave_incl_scan_u32(nb), kx = kin - nb;
-                nrounds = (unsigned)__builtin_amdgcn_readlane((int)kin, 63);
-                if (nrounds > (unsigned)MAXROUNDS) fallback = true;
-                else {
-                    lds_fence();
-                    ccur[2 * lane] = b0;
-                    ccur[2 * lane + 1] = b1;
-                    if (f0) rtab[kx] = (unsigned short)(2 * lane);
-                    if (f1) rtab[kx + f0] = (unsigned short)(2 * lane + 1);
-                    if (lane == 0) {
-                        rtab[nrounds] = (unsigned short)NCLS;
-                        sp[0] = xmin;
-                        const double w0 = sp[1] - xmin, w1 = xmax - sp[127];
-                        double v0 = (w0 > 0.0 && w0 < inf) ? 1.0 / w0 : 0.0, v1 = (w1 > 0.0 && w1 < inf) ? 1.0 / w1 : 0.0;
-                        iw[0] = (v0 < inf) ? v0 : 0.0;
-                        iw[127] = (v1 < inf) ? v1 : 0.0;
-                    }
-                    lds_fence();
-                }
-            }
-        }
+        ph_classify<T>(wbase);
+        bool fb = rfl(ws->fallback) != 0;
         WDBG(20);
-        if (wa.stop == 2) skip = true;
-        // ================================================================ pass B: the slice, class-sorted, into the scratch
-        if (!fallback && !skip)
-        for (unsigned c = 0; c < C; ++c) {
-            const WV_GA T* xc = xp + (long long)c * cs;
-            const unsigned eb = c * D;
-            for (unsigned d0 = 0; d0 < D; d0 += 256u) {
-                double v[4];
-                unsigned cl[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned d = d0 + 64u * u + (unsigned)lane;
-                    const unsigned dd = d < D ? d : D - 1u;
-                    v[u] = (double)xc[dd];
-                    cl[u] = clsb[eb + dd];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned d = d0 + 64u * u + (unsigned)lane;
-                    if (d < D) {
-                        const unsigned pos = atomicAdd(&ccur[cl[u]], 1u);
-                        unsigned k = 0u;
-                        for (unsigned kk = 1u; kk < s; ++kk) k += (d >= row0(kk)) ? 1u : 0u;
-                        const unsigned slot = (d < row0(k) + niter) ? c * s + k : 255u;
-                        sv[pos] = v[u];
-                        st[pos] = (eb + d) | (slot << 16) | (cl[u] << 24);
+        if (!fb && stop != 1) {
+            ph_partition<T>(wbase);
+            WDBG(30);
+            if (stop != 2) {
+                ph_rounds<T>(wbase);
+                WDBG(40);
+                if (stop != 3) {
+                    if (kp.need_rt) { ph_fold<T>(wbase); fb = rfl(ws->fallback) != 0; }
+                    WDBG(50);
+                    if (!fb && stop != 4) {
+                        if (kp.need_eb || kp.need_rb) ph_series<T>(wbase);
+                        WDBG(60);
+                        if (kp.need_et && kp.ess_ok && stop != 5) ph_indicators<T>(wbase);
                     }
                 }
             }
         }
-        mem_fence();
-
-        WDBG(30);
-        if (wa.stop == 3) skip = true;
-        // ================================================================ the rounds
-        unsigned tp[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // 0-based places of the order statistics: median pair first, then the quantile pairs
-        int ntgt = 0;
-        {
-            const unsigned ql0 = (unsigned)(kp.q_j[0] - 1), ql1 = (unsigned)kp.q_j[0], qh0 = (unsigned)(kp.q_j[1] - 1), qh1 = (unsigned)kp.q_j[1];
-            if (need_med && need_q) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; tp[2] = ql0; tp[3] = ql1; tp[4] = qh0; tp[5] = qh1; ntgt = 6; }
-            else if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; ntgt = 2; }
-            else if (need_q) { tp[0] = ql0; tp[1] = ql1; tp[2] = qh0; tp[3] = qh1; ntgt = 4; }
-        }
-        unsigned anyodd = 0u;
-        if (fallback || skip) nrounds = 0u;
-        for (unsigned r = 0; r < nrounds; ++r) {
-            const unsigned cA = rflu((unsigned)rtab[r]), cB = rflu((unsigned)rtab[r + 1]);
-            const unsigned g0 = cA ? rflu(ccur[cA - 1u]) : 0u, g1 = rflu(ccur[cB - 1u]);
-            const unsigned M = g1 - g0;
-            if (M == 0u) continue;
-            const unsigned ncls = cB - cA;
-            const unsigned sh = 31u - (unsigned)__clz((int)((unsigned)NBIN / ncls));
-            const double fsub = (double)((1u << sh) - 1u), fcap = (double)((1u << sh) - 2u);
-#pragma unroll
-            for (int q = 0; q < NBIN / 2 / 64; ++q) cnt[lane + 64 * q] = 0u;
-            double v[8];
-            unsigned tg[8], bn[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned idx = 64u * i + (unsigned)lane;
-                const unsigned src = g0 + (idx < M ? idx : 0u);
-                v[i] = sv[src];
-                tg[i] = st[src];
-            }
-            {
-                double lo[8], wd[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = iw[cls]; }
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const unsigned cls = tg[i] >> 24;
-                    double f = (v[i] - lo[i]) * wd[i] * fsub;
-                    f = f < fcap ? f : fcap;
-                    const unsigned sub = (v[i] == lo[i]) ? 0u : 1u + (unsigned)(int)f;
-                    bn[i] = (((cls - cA) << sh) + sub) | ((sub == 0u ? 1u : 0u) << 15);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned b = bn[i] & 0x7FFFu;
-                if (64u * i + (unsigned)lane < M) atomicAdd(&cnt[b >> 1], 1u << ((b & 1u) << 4));
-            }
-            lds_fence();
-            { // exclusive prefix over the packed counters: 8 bins per lane
-                unsigned wv[4], s8[8], tot = 0u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) wv[q] = cnt[4 * lane + q];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const unsigned c8 = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu; s8[q] = tot; tot += c8; }
-                const unsigned incl = wave_incl_scan_u32(tot), bb = incl - tot;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) cnt[4 * lane + q] = (bb + s8[2 * q]) | ((bb + s8[2 * q + 1]) << 16);
-            }
-            lds_fence();
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (64u * i + (unsigned)lane < M) {
-                    const unsigned b = bn[i] & 0x7FFFu, shb = (b & 1u) << 4;
-                    const unsigned pos = (atomicAdd(&cnt[b >> 1], 1u << shb) >> shb) & 0xFFFFu;
-                    val[pos] = v[i];
-                    tagl[pos] = tg[i];
-                    binid[pos] = (unsigned short)bn[i];
-                }
-            }
-            lds_fence();
-            // any target order statistic in this round?
-            bool tin = false;
-#pragma unroll
-            for (int t = 0; t < 6; ++t) tin = tin || (t < ntgt && tp[t] >= g0 && tp[t] < g1);
-            // dense count in slot order: tied rank, place in sorted order
-            for (unsigned i = 0; 64u * i < M; ++i) {
-                const unsigned sl = 64u * i + (unsigned)lane;
-                if (sl < M) {
-                    const double x = val[sl];
-                    const unsigned tgv = tagl[sl];
-                    const unsigned bb = binid[sl], b = bb & 0x7FFFu, bm = b > 0u ? b - 1u : 0u;
-                    const unsigned wa_ = cnt[b >> 1], wb_ = cnt[bm >> 1];
-                    const unsigned en = (b & 1u) ? wa_ >> 16 : wa_ & 0xFFFFu;
-                    const unsigned sb_ = (b == 0u) ? 0u : ((bm & 1u) ? wb_ >> 16 : wb_ & 0xFFFFu);
-                    const bool rsv = (bb >> 15) != 0u;
-                    unsigned less = sb_, eq;
-                    if (rsv) {
-                        eq = en - sb_;
-                    } else {
-                        eq = 0u;
-                        const unsigned last = en - 1u;
-                        for (unsigned m2 = sb_; m2 <= last; m2 += 4u) {
-                            const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
-                            const double y0 = val[m2];
-                            const double y1 = val[i1 <= last ? i1 : last];
-                            const double y2 = val[i2 <= last ? i2 : last];
-                            const double y3 = val[i3 <= last ? i3 : last];
-                            less += (y0 < x) ? 1u : 0u;
-                            eq += (y0 == x) ? 1u : 0u;
-                            less += (i1 <= last && y1 < x) ? 1u : 0u;
-                            eq += (i1 <= last && y1 == x) ? 1u : 0u;
-                            less += (i2 <= last && y2 < x) ? 1u : 0u;
-                            eq += (i2 <= last && y2 == x) ? 1u : 0u;
-                            less += (i3 <= last && y3 < x) ? 1u : 0u;
-                            eq += (i3 <= last && y3 == x) ? 1u : 0u;
-                        }
-                    }
-                    const unsigned gl = g0 + less;
-                    const unsigned r2 = 2u * gl + eq + 1u; // doubled tied rank: (first + last place) of the run, 1-based
-                    anyodd |= r2 & 1u;                      // (a tie group of even size has a half-integer rank: odd doubled value)
-                    if (tin) {
-#pragma unroll
-                        for (int t = 0; t < 6; ++t)
-                            if (t < ntgt && tp[t] - gl < eq) ostat[t] = x;
-                    }
-                    unsigned pos = gl;
-                    if (eq != 1u) {
-                        if (rsv) pos += sl - sb_;
-                        else for (unsigned m2 = sb_; m2 < sl; ++m2) pos += (val[m2] == x) ? 1u : 0u;
-                    }
-                    if (need_bulk) ra[tgv & 0xFFFFu] = (unsigned short)r2;
-                    sv[pos] = x;
-                    st[pos] = (tgv >> 16) & 0xFFu;
-                }
-            }
-            lds_fence();
-        }
-        anyodd = (__ballot(anyodd != 0u) != 0ull) ? 1u : 0u;
-        mem_fence();
-
-        WDBG(40);
-        if (wa.stop == 4) skip = true;
-        // ================================================================ order statistics -> median / quantiles, in T
-        T medT = (T)0, qloT = (T)0, qhiT = (T)0;
-        {
-            int t = 0;
-            if (need_med) {
-                const T a = (T)ostat[0], b = (T)ostat[1];
-                medT = (n & 1u) ? a : (T)(a / (T)2 + b / (T)2); // Statistics.median: a/2 + b/2
-                t = 2;
-            }
-            if (need_q) {
-                T qq[2];
-                for (int i = 0; i < 2; ++i) {
-                    const T a = (T)ostat[t + 2 * i], b = (T)ostat[t + 2 * i + 1];
-                    const T g = (T)kp.q_g[i];
-                    const bool fin = (a - a == (T)0) && (b - b == (T)0);
-                    qq[i] = fin ? (T)(a + (T)(g * (T)(b - a))) : (T)((T)(((T)1 - g) * a) + (T)(g * b));
-                }
-                qloT = qq[0];
-                qhiT = qq[1];
-            }
-        }
-        double eb_ = nan, rb_ = nan, et_ = nan, rt_ = nan;
-
-        // ================================================================ fold: rhat(kind = tail) as a merge of the sorted copy
-        if (kp.need_rt && !fallback && !skip) {
-            auto fold = [&](double x) -> double {
-                const T d = (T)((T)x - medT);
-                return (double)(d < (T)0 ? -d : d);
-            };
-            const unsigned h = (n - 1u) / 2u;
-            int zero = 0;
-            asm volatile("" : "+v"(zero));
-            const unsigned imed = rflu(((T)sv[h + zero] == medT) ? h : h + 1u);
-            bool ok;
-            {
-                const double below = sv[(imed > 0u ? imed - 1u : 0u) + zero], at = sv[(imed < n ? imed : n - 1u) + zero];
-                ok = (imed == 0u || (T)below <= medT) && (imed == n || (T)at >= medT);
-                const double f0 = fold(sv[zero]), f1 = fold(sv[n - 1u + zero]);
-                ok = ok && f0 < inf && f1 < inf;
-                ok = rfl(ok ? 1 : 0) != 0;
-            }
-            const unsigned nA = imed, nB = n - imed;
-#pragma unroll
-            for (int q = 0; q < 2 * WV_MAXM * 8 / 64; ++q) facc[lane + 64 * q] = 0;
-            if (lane < WV_MAXM) { tor[lane] = 0ull; tand[lane] = ~0ull; tcnt[lane] = 0u; }
-            if (lane == 0) *tln = 0u;
-            const unsigned cp = (unsigned)lane & 7u;
-            unsigned a0 = 0u, b0 = 0u;
-            for (unsigned k0 = 0; ok && k0 < n; k0 += (unsigned)FT) {
-                const unsigned cntk = (n - k0 < (unsigned)FT) ? n - k0 : (unsigned)FT;
-                // stage both pieces: entry q + 1 = member q of the piece, q = -1 .. FT; -inf in front of a run, +inf behind it
-                {
-                    double xa[5], xb[5];
-                    unsigned la[5], lb[5];
-                    bool va[5], vb[5];
-                    int qq[5];
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        int q = 64 * i + lane;
-                        if (i == 4) q = (lane == 0) ? -1 : ((lane == 1) ? FT : -2);
-                        qq[i] = q;
-                        const long long ia = (long long)a0 + q, ib = (long long)b0 + q;
-                        va[i] = q >= -1 && ia >= 0 && ia < (long long)nA;
-                        vb[i] = q >= -1 && ib >= 0 && ib < (long long)nB;
-                        const unsigned srcA = va[i] ? (unsigned)((long long)imed - 1 - ia) : 0u;
-                        const unsigned srcB = vb[i] ? (unsigned)((long long)imed + ib) : 0u;
-                        xa[i] = sv[srcA]; la[i] = st[srcA];
-                        xb[i] = sv[srcB]; lb[i] = st[srcB];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) {
-                        const int q = qq[i];
-                        if (q >= -1) {
-                            fa[q + 1] = va[i] ? fold(xa[i]) : (q < 0 ? -inf : inf);
-                            fb[q + 1] = vb[i] ? fold(xb[i]) : (q < 0 ? -inf : inf);
-                            sa[q + 1] = (unsigned char)la[i];
-                            sb[q + 1] = (unsigned char)lb[i];
-                        }
-                    }
-                }
-                // the scores of this lane's four merged positions: position p has rank p + 1 unless it has equals
-                const unsigned d = 4u * (unsigned)lane;
-                double zq[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const unsigned pp = k0 + d + (unsigned)i; zq[i] = (double)gzd[(pp < n ? pp : n - 1u) + 1u]; }
-                lds_fence();
-                unsigned ataken = 0u;
-                if (d < cntk) {
-                    // diagonal: members of A among the first d outputs of the tile (A first on ties)
-                    unsigned lo = 0u, hi = d;
-                    while (lo < hi) {
-                        const unsigned mid = (lo + hi) >> 1;
-                        if (fa[1u + mid] <= fb[d - mid]) lo = mid + 1u; else hi = mid;
-                    }
-                    unsigned a = lo, b = d - lo;
-                    const double pa = fa[a], pb = fb[b];
-                    double prev = pa > pb ? pa : pb;
-                    double ca = fa[1u + a], cb = fb[1u + b];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const bool ta = ca <= cb;
-                        const double cur = ta ? ca : cb;
-                        const unsigned slot = ta ? (unsigned)sa[1u + a] : (unsigned)sb[1u + b];
-                        a += ta ? 1u : 0u;
-                        b += ta ? 0u : 1u;
-                        const double nx = ta ? fa[1u + a] : fb[1u + b];
-                        ca = ta ? nx : ca;
-                        cb = ta ? cb : nx;
-                        const double nxt = ca < cb ? ca : cb;
-                        if (d + (unsigned)i < cntk) {
-                            ataken += ta ? 1u : 0u;
-                            if (cur == prev || cur == nxt) { // equals exist: exact count after the tiles
-                                const unsigned ti = atomicAdd(tln, 1u);
-                                if (ti < (unsigned)WTCAP) { tval[ti] = cur; tsl[ti] = (unsigned char)slot; }
-                            } else if (slot < (unsigned)m) {
-                                const double zv = zq[i];
-                                atomicAdd((unsigned long long*)&facc[slot * 8u + cp], (unsigned long long)fx.u(zv));
-                                atomicAdd((unsigned long long*)&facc[WV_MAXM * 8 + slot * 8u + cp], (unsigned long long)fx.uu(zv * zv));
-                            }
-                        }
-                        prev = cur;
-                    }
-                }
-                const unsigned asum = (unsigned)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(ataken), 63);
-                a0 += asum;
-                b0 = k0 + cntk - a0;
-                lds_fence();
-            }
-            unsigned nt = 0u;
-            if (ok) { nt = rflu(*tln); if (nt > (unsigned)WTCAP) ok = false; }
-            if (!ok) { fallback = true; nt = 0u; }
-            // members with equals: exact tied rank from both runs (binary searches in the sorted copy)
-            if ((unsigned)lane < nt) {
-                auto count_run = [&](double f, bool arun, bool le) -> unsigned {
-                    unsigned lo = 0u, hi = arun ? nA : nB;
-                    while (lo < hi) {
-                        const unsigned mid = (lo + hi) >> 1;
-                        const double x = fold(arun ? sv[imed - 1u - mid] : sv[imed + mid]);
-                        if (le ? (x <= f) : (x < f)) lo = mid + 1u; else hi = mid;
-                    }
-                    return lo;
-                };
-                const double cur = tval[lane];
-                const unsigned slot = tsl[lane];
-                const unsigned lA = count_run(cur, true, false), lB = count_run(cur, false, false);
-                const unsigned eA = count_run(cur, true, true), eB = count_run(cur, false, true);
-                const unsigned less = lA + lB, eq = (eA - lA) + (eB - lB);
-                const double zv = (double)gz[2u * less + eq + 1u];
-                if (slot < (unsigned)m) {
-                    atomicAdd((unsigned long long*)&facc[slot * 8u + cp], (unsigned long long)fx.u(zv));
-                    atomicAdd((unsigned long long*)&facc[WV_MAXM * 8 + slot * 8u + cp], (unsigned long long)fx.uu(zv * zv));
-                    const unsigned long long zb = (unsigned long long)__double_as_longlong(zv);
-                    atomicOr(&tor[slot], zb);
-                    atomicAnd(&tand[slot], zb);
-                    atomicAdd(&tcnt[slot], 1u);
-                }
-            }
-            lds_fence();
-            if (lane < m) { // sums -> moments: the expressions of fold_merge_phase (mdt_fold.inc)
-                long long s1 = 0, s2 = 0;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) { s1 += facc[lane * 8 + c]; s2 += facc[WV_MAXM * 8 + lane * 8 + c]; }
-                const double S1 = (double)s1 * fx.i1, S2 = (double)s2 * fx.i2;
-                const double mu = S1 / dn;
-                const bool constant = niter == 1u || (tcnt[lane] == niter && tor[lane] == tand[lane]);
-                mean_j[lane] = mu;
-                var_j[lane] = constant ? 0.0 : (S2 - mu * S1) / (dn - 1.0);
-            }
-            lds_fence();
-            rt_ = combine_moments(mean_j, var_j, m, kp.cf).rhat;
-            lds_fence();
-        }
-
-        WDBG(50);
-        if (wa.stop == 5) skip = true;
-        // ================================================================ bulk series: moments, lag products, Geyer's scan
-        if (need_bulk && !fallback && !skip) {
-            const bool acov = kp.need_eb && kp.ess_ok;
-            const unsigned nblk = (niter + 63u) >> 6;
-            const int c_hi = 16 * ((int)maxlag / 16 + 1);
-            for (int k = lane; k < 256; k += 64) lagA[k] = 0.0;
-            WB wbm = {0.0, 0.0, 0.0};
-            // Geyer's state (src/ess_rhat.jl:555-594), every lane the same
-            double pt = 0.0, gsum = 0.0;
-            long long gk = 0;
-            bool started = false, done = false;
-            long long k0 = 0;
-            int block = 0;
-            while (true) {
-                long long kend = k0 + 16 * (ZT - 1);
-                if (kend > maxlag + 1) kend = maxlag + 1;
-                int cb[ZT];
-#pragma unroll
-                for (int i = 0; i < ZT; ++i) { const int c = (int)k0 + 16 * i; cb[i] = c < c_hi ? c : c_hi; }
-                for (unsigned t = 64u * nblk + (unsigned)lane; t < (unsigned)STG; t += 64u) stage[t] = 0.0; // zeros behind every chain
-                d4 acc[ZT];
-#pragma unroll
-                for (int i = 0; i < ZT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
-                for (int j = 0; j < m; ++j) {
-                    const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
-                    const WV_GA unsigned short* rj = ra + (c * D + row0(k));
-                    double K = 0.0;
-                    long long a1 = 0, a2 = 0;
-                    const double mu0 = (block > 0) ? mu_j[j] : 0.0;
-                    for (unsigned b = 0; b < nblk; ++b) {
-                        const unsigned t = 64u * b + (unsigned)lane;
-                        const bool okt = t < niter;
-                        const unsigned r2 = rj[okt ? t : niter - 1u];
-                        double z = (double)lz[r2 >> 1];
-                        if (anyodd) { if (r2 & 1u) z = (double)gz[r2]; } // a half-integer rank: the table by doubled rank
-                        if (b == 0u) K = readlane_d(z, 0);
-                        const double u = okt ? z - K : 0.0;
-                        if (block == 0) {
-                            a1 += okt ? fx.u(u) : 0;
-                            a2 += okt ? fx.uu(u * u) : 0;
-                            stage[t] = u;
-                        } else {
-                            stage[t] = okt ? u - mu0 : 0.0;
-                        }
-                    }
-                    if (block == 0) {
-                        // exact integer sums; the expressions of series_z_phase: bit-identical means and variances, hence R-hat
-                        const double S1 = (double)wave_sum_i64(a1) * fx.i1, S2 = (double)wave_sum_i64(a2) * fx.i2;
-                        const double mu = S1 / dn;
-                        const double Cc = S2 - mu * S1;
-                        if (lane == 0) { var_j[j] = Cc / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
-                        if (acov) {
-                            lds_fence();
-                            for (unsigned b = 0; b < nblk; ++b) {
-                                const unsigned t = 64u * b + (unsigned)lane;
-                                if (t < niter) stage[t] -= mu;
-                            }
-                        }
-                    }
-                    if (acov) {
-                        lds_fence();
-                        // lag products of the centred chain (src/ess_rhat.jl:170-178) as blocked Hankel tiles: A = u[64 b + lane],
-                        // B = the same 64 values shifted by the tile's base; lag c + j - i sits at (i, j) of the tile with base c
-                        for (unsigned b = 0; b < nblk; ++b) {
-                            const double* pb = stage + 64u * b + (unsigned)lane;
-                            const double a = pb[0];
-#pragma unroll
-                            for (int i = 0; i < ZT; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pb[cb[i]], acc[i], 0, 0, 0);
-                        }
-                    }
-                    lds_fence();
-                }
-                if (block == 0) wbm = combine_moments(mean_j, var_j, m, kp.cf);
-                if (!acov) break;
-                // the diagonals of the tiles: lane e holds strip lag e - 15 (relative to k0)
-                {
-                    double sdiag = 0.0;
-                    double* stg = stage;
-#pragma unroll
-                    for (int i = 0; i < ZT; ++i) {
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) stg[((lane >> 4) + 4 * rg) * 17 + (lane & 15)] = acc[i][rg];
-                        lds_fence();
-                        const int dd = lane - 16 * i;
-                        if (dd >= 0 && dd <= 30) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int jj = r + dd - 15;
-                                if (jj >= 0 && jj < 16) sdiag += stg[r * 17 + jj];
-                            }
-                        }
-                        lds_fence();
-                    }
-                    const long long kq = k0 + lane - 15;
-                    if (lane >= 15 && kq < kend) lagA[kq] = sdiag;
-                    lds_fence();
-                }
-                // Geyer's initial monotone sequence over the lags available so far
-                {
-                    const double W = wbm.W, inv_varp = 1.0 / wbm.varp;
-                    auto rho = [&](long long k) -> double {
-                        const double ma = lagA[k] / dm / dn;
-                        return 1.0 - inv_varp * (W - ma);
-                    };
-                    const long long avail = kend - 1;
-                    if (!started) {
-                        pt = 1.0 + rho(1);
-                        gsum = pt;
-                        gk = 2;
-                        started = true;
-                    }
-                    int stop = 0;
-                    while (gk < maxlag - 1) {
-                        if (gk + 1 > avail) break;
-                        const double delta = rho(gk) + rho(gk + 1);
-                        if (!(delta > 0.0)) { stop = 1; break; }
-                        pt = jl_min(delta, pt);
-                        gsum += pt;
-                        gk += 2;
-                    }
-                    if (!(gk < maxlag - 1)) stop = 1;
-                    if (stop && (gk <= avail || !(maxlag > 1))) {
-                        const double rho_even = (maxlag > 1) ? rho(gk) : 0.0;
-                        const double tau = jl_max(0.0, 2.0 * gsum + jl_max(0.0, rho_even) - 1.0);
-                        double e = jl_min(1.0 / tau, kp.rel_ess_max);
-                        if (!kp.relative) e *= kp.ntotal;
-                        eb_ = e;
-                        done = true;
-                    }
-                }
-                if (rfl(done ? 1 : 0)) break;
-                k0 = kend;
-                ++block;
-            }
-            rb_ = wbm.rhat;
-            if (acov && kp.method == 1) { // FFTAutocovMethod normalises by the chain's own lag 0: 0/0 = NaN for a constant split chain (src/ess_rhat.jl:192)
-                bool anyc = false;
-                for (int j = 0; j < m; ++j) anyc = anyc || (var_j[j] == 0.0);
-                if (anyc) eb_ = nan;
-            }
-            if (!acov) eb_ = nan;
-            lds_fence();
-        }
-
-        WDBG(60);
-        if (wa.stop == 6) skip = true;
-        // ================================================================ tail ESS: indicators of x <= q (src/ess_rhat.jl:301-311, 647-659)
-        if (kp.need_et && kp.ess_ok && !fallback && !skip) {
-            const int nwS = (int)((niter + 63u) >> 6);
-            const int nwU = nwS + (int)(maxlag >> 6) + 2;
-            for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull;
-            for (int i = lane; i < 2 * 256; i += 64) icov[i] = 0.0;
-            lds_fence();
-            for (int j = 0; j < m; ++j) {
-                const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
-                const WV_GA T* xr = xp + (long long)c * cs + row0(k);
-                for (int i = 0; i < nwS; ++i) {
-                    const unsigned t = 64u * (unsigned)i + (unsigned)lane;
-                    const bool okt = t < niter;
-                    const T xv = xr[okt ? t : niter - 1u];
-                    const unsigned long long q0 = __ballot(okt && xv <= qloT), q1 = __ballot(okt && xv <= qhiT);
-                    if (lane == 0) { sb2[(2 * j) * nwU + i] = q0; sb2[(2 * j + 1) * nwU + i] = q1; }
-                    __builtin_amdgcn_wave_barrier(); // (every lane joins before the next ballot: see the end of the ticket loop)
-                }
-            }
-            lds_fence();
-            // lanes 0 / 1 run Geyer's scan of indicator 0 / 1
-            double ipt = 0.0, isum = 0.0, iess = nan;
-            long long ik = 0;
-            bool istarted = false, idone = lane >= 2;
-            const int kl = lane & 15, seg = lane >> 4;
-            const int wq = (nwS + 3) >> 2, i0 = seg * wq, i1 = (i0 + wq < nwS) ? i0 + wq : nwS;
-            long long k0 = 0;
-            while (true) {
-                long long kend = k0 + 16;
-                if (kend > maxlag + 1) kend = maxlag + 1;
-                const long long k = k0 + kl;
-                double cov0 = 0.0, cov1 = 0.0;
-                for (int u = 0; u < 2 * m; ++u) {
-                    const unsigned long long* sbu = sb2 + u * nwU;
-                    int sxp = 0, akp = 0;
-                    if (k < kend) {
-                        const int q = (int)(k >> 6), r = (int)(k & 63);
-                        unsigned long long lo = sbu[i0 + q];
-                        for (int i = i0; i < i1; ++i) {
-                            const unsigned long long v = sbu[i];
-                            const unsigned long long hi = sbu[i + q + 1];
-                            const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
-                            sxp += __popcll(v);
-                            akp += __popcll(v & vs);
-                            lo = hi;
-                        }
-                    }
-                    sxp += __shfl_xor(sxp, 16); sxp += __shfl_xor(sxp, 32);
-                    akp += __shfl_xor(akp, 16); akp += __shfl_xor(akp, 32);
-                    if (k < kend && seg == 0) {
-                        const long long Sx = sxp, Ak = akp, ni = (long long)niter;
-                        const int q = (int)(k >> 6);
-                        long long head = 0, tail = 0; // ones among the first k / the last k positions
-                        for (int i = 0; i <= q; ++i) {
-                            const long long nb2 = k - ((long long)i << 6);
-                            const unsigned long long mk = nb2 >= 64 ? ~0ull : (nb2 <= 0 ? 0ull : ((1ull << nb2) - 1ull));
-                            head += __popcll(sbu[i] & mk);
-                        }
-                        {
-                            const long long p0 = ni - k;
-                            for (int i = (int)((p0 > 0 ? p0 : 0) >> 6); i < nwS; ++i) {
-                                const long long bpos = (long long)i << 6;
-                                const long long sk = p0 - bpos;
-                                const unsigned long long mk = sk <= 0 ? ~0ull : (sk >= 64 ? 0ull : ~((1ull << sk) - 1ull));
-                                tail += __popcll(sbu[i] & mk);
-                            }
-                        }
-                        const long long Tk = Sx - head, Hk = Sx - tail;
-                        const long long N = ni * ni * Ak - ni * Sx * (Hk + Tk) + (ni - k) * Sx * Sx;
-                        double ck = (double)N / (dn * dn);
-                        if (kp.method == 1 && k > 0 && (Sx == 0 || Sx == ni)) ck = nan;
-                        if (k == 0) imean[(u & 1) * WV_MAXM + (u >> 1)] = (double)Sx / dn;
-                        cov0 += (u & 1) ? 0.0 : ck;
-                        cov1 += (u & 1) ? ck : 0.0;
-                    }
-                    __builtin_amdgcn_wave_barrier(); // (every lane joins before the next unit's shuffles)
-                }
-                if (k < kend && seg == 0) { icov[k] = cov0; icov[256 + k] = cov1; }
-                lds_fence();
-                if (!idone) {
-                    const int ind = lane;
-                    const double* cv = icov + ind * 256;
-                    const double W = cv[0] / dm / (double)(niter - 1u);
-                    double mb = 0.0;
-                    for (int j = 0; j < m; ++j) mb += imean[ind * WV_MAXM + j];
-                    mb /= dm;
-                    double vb = 0.0;
-                    for (int j = 0; j < m; ++j) { const double dd = imean[ind * WV_MAXM + j] - mb; vb = fma(dd, dd, vb); }
-                    vb /= (double)(m > 1 ? m - 1 : m);
-                    const double varp = kp.cf * W + vb;
-                    const double inv_varp = 1.0 / varp;
-                    auto rho = [&](long long kk) -> double {
-                        const double ma = cv[kk] / dm / dn;
-                        return 1.0 - inv_varp * (W - ma);
-                    };
-                    const long long avail = kend - 1;
-                    if (!istarted) { ipt = 1.0 + rho(1); isum = ipt; ik = 2; istarted = true; }
-                    int stop = 0;
-                    while (ik < maxlag - 1) {
-                        if (ik + 1 > avail) break;
-                        const double delta = rho(ik) + rho(ik + 1);
-                        if (!(delta > 0.0)) { stop = 1; break; }
-                        ipt = jl_min(delta, ipt);
-                        isum += ipt;
-                        ik += 2;
-                    }
-                    if (!(ik < maxlag - 1)) stop = 1;
-                    if (stop && (ik <= avail || !(maxlag > 1))) {
-                        const double rho_even = (maxlag > 1) ? rho(ik) : 0.0;
-                        const double tau = jl_max(0.0, 2.0 * isum + jl_max(0.0, rho_even) - 1.0);
-                        double e = jl_min(1.0 / tau, kp.rel_ess_max);
-                        if (!kp.relative) e *= kp.ntotal;
-                        iess = e;
-                        idone = true;
-                    }
-                }
-                if (__ballot(!idone) == 0ull) break;
-                k0 = kend;
-            }
-            et_ = jl_min(readlane_d(iess, 0), readlane_d(iess, 1));
-            lds_fence();
-        }
-
         WDBG(70);
-        if (fallback) { // the general kernel, queued behind this launch, serves the parameter
+        if (fb) { // the general kernel, queued behind this launch, serves the parameter
             if (lane == 0) { const int i = atomicAdd(wa.fb_count, 1); wa.fb_list[i] = (unsigned)p; }
         } else if (lane == 0) {
+            const double eb_ = ws->out[0], rb_ = ws->out[1], et_ = ws->out[2], rt_ = ws->out[3];
             store_out<T>(kp.out_eb, p, eb_);
             store_out<T>(kp.out_rb, p, rb_);
             store_out<T>(kp.out_et, p, et_);
             store_out<T>(kp.out_rt, p, rt_);
             store_out<T>(kp.out_rrank, p, jl_max(rt_, rb_)); // map(max, Rtail, Rbulk), src/ess_rhat.jl:419,622
         }
-        WDBG(71);
+        WPROF(9);
         // Every lane joins here before the next ticket: without a convergent operation behind the last lane-0 block the compiler
         // sends lanes 1..63 straight back to the loop head (they have nothing to store) and the next iteration runs without lane 0
         // -- no ticket is drawn, parameter 0 is worked on again, for ever.  (Found with the progress words, round 5.)
         lds_fence();
     }
+#ifdef WV_PROF
+    if (wa.dbg && lane < 16) ((unsigned long long*)(wa.dbg + 8192))[gw * 16 + lane] = ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane];
+#endif
     WDBG(0xFFFF);
 }
 
