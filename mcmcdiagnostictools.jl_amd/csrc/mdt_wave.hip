@@ -76,12 +76,10 @@ constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
 static_assert(WV_MAXN <= WR * 8, "the time-order class bytes of passes A / B live in the image");
 // fold view
-constexpr int FE = FT + 2;                             // staged entries of a piece: the member in front of it, FT members at most, the member behind it
-constexpr int OFF_FA = OFF_VIEW;                       // double fa[FE], fb[FE]: entry e = member e - 1 of the tile's piece
-constexpr int OFF_FB = OFF_FA + FE * 8;
-constexpr int OFF_SA = OFF_FB + FE * 8;                // uint8 sa[FE], sb[FE]: their split-chain slots
-constexpr int OFF_SB = OFF_SA + ((FE + 7) / 8) * 8;
-constexpr int OFF_FACC = OFF_SB + ((FE + 7) / 8) * 8;  // int64 facc[2][16][8]
+constexpr int FE = FT + 4;                             // staged entries of a tile: for each piece the member in front of it, its members, the one behind
+constexpr int OFF_FA = OFF_VIEW;                       // double fv[FE]
+constexpr int OFF_SA = OFF_FA + FE * 8;                // uint8 fs[FE]: their split-chain slots
+constexpr int OFF_FACC = OFF_SA + ((FE + 7) / 8) * 8;  // int64 facc[2][16][8]
 constexpr int OFF_TOR = OFF_FACC + 2 * WV_MAXM * 8 * 8; // uint64 tor[16], tand[16]
 constexpr int OFF_TCNT = OFF_TOR + 2 * WV_MAXM * 8;    // unsigned tcnt[16], tln, pad
 constexpr int OFF_TB = OFF_TCNT + (WV_MAXM + 2) * 4;   // unsigned tb[WV_MAXN / FT + 2]: members of A in front of every tile
@@ -102,9 +100,27 @@ constexpr int PERWAVE = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER, END_IN
 constexpr int VIEW_BYTES = PERWAVE - OFF_VIEW;
 constexpr int LDS_TOTAL = 160 * 1024;
 
+// one member of the slice in the per-wave scratch, 12 bytes (one store / one load per member): its value and a tag -- in the
+// class-sorted copy element | split-chain slot << 16 | class << 24, in the sorted copy the split-chain slot
+struct __attribute__((packed, aligned(4))) Rec { double v; unsigned t; };
+static_assert(sizeof(Rec) == 12, "12-byte scratch records");
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
+// one 12-byte store per record (global_store_dwordx3: the compiler would split the packed struct into an 8- and a 4-byte
+// store, i.e. two requests per lane of a scattered store); ordered against later loads by mem_fence() like every store here
+__device__ __forceinline__ void rec_store(__attribute__((address_space(1))) Rec* p, double v, unsigned t) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    u3v w;
+    w.x = (unsigned)b; w.y = (unsigned)(b >> 32); w.z = t;
+    asm volatile("global_store_dwordx3 %0, %1, off" : : "v"(p), "v"(w) : "memory");
+}
+__device__ __forceinline__ Rec rec_load(const __attribute__((address_space(1))) Rec* p) {
+    Rec r;
+    r.v = p->v;
+    r.t = p->t;
+    return r;
+}
 struct WvArgs {
-    double* sv;            // [waves][npad]: class-sorted values, then (in place, round by round) the sorted slice
-    unsigned* st;          // [waves][npad]: tags (element | slot << 16 | class << 24), then the split-chain slot of every sorted member
+    Rec* rec;              // [waves][npad]: the slice class-sorted, then (in place, round by round) sorted
     unsigned short* ra;    // [waves][npad]: doubled tied rank of every element, time order
     unsigned* fb_list;     // parameters left to the general kernel
     int* fb_count;
@@ -119,7 +135,7 @@ struct WvArgs {
 // lane of a spill register); their only argument is the LDS address of the wave's block.
 struct WS {
     unsigned long long kp;            // const KP* (read through the constant address space)
-    unsigned long long sv, st, ra;    // the wave's scratch
+    unsigned long long rec, ra;       // the wave's scratch
     unsigned long long xp;            // the parameter's slice
     unsigned long long dbg;           // progress words, or 0
     long long p;                      // the parameter
@@ -434,8 +450,7 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
     WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
     WV_LA unsigned char* clsb = (WV_LA unsigned char*)(wb + OFF_VAL);
     const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
-    WV_GA double* sv = (WV_GA double*)rfl64(ws->sv);
-    WV_GA unsigned* st = (WV_GA unsigned*)rfl64(ws->st);
+    WV_GA Rec* rec = (WV_GA Rec*)rfl64(ws->rec);
     const unsigned D = (unsigned)kp.D, C = (unsigned)kp.C;
     const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
     const long long cs = kp.cstride;
@@ -471,8 +486,7 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
                 for (unsigned kk = 1u; kk < s; ++kk) k += (ra_.d >= row0(kk)) ? 1u : 0u;
                 const unsigned c = (r < NRW ? r : NRW - 1u) / rpc;
                 const unsigned slot = (ra_.d < row0(k) + niter) ? c * s + k : 255u; // (255: a row the split drops)
-                sv[pos] = v[u];
-                st[pos] = (ra_.eb + ra_.d) | (slot << 16) | (cl[u] << 24);
+                rec_store(rec + pos, v[u], (ra_.eb + ra_.d) | (slot << 16) | (cl[u] << 24));
             }
         }
     }
@@ -493,8 +507,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     WV_LA unsigned* tagl = (WV_LA unsigned*)(wb + OFF_TAG);
     WV_LA unsigned short* binid = (WV_LA unsigned short*)(wb + OFF_BIN);
     WV_LA unsigned* cnt = (WV_LA unsigned*)(wb + OFF_CNT);
-    WV_GA double* sv = (WV_GA double*)rfl64(ws->sv);
-    WV_GA unsigned* st = (WV_GA unsigned*)rfl64(ws->st);
+    WV_GA Rec* rec = (WV_GA Rec*)rfl64(ws->rec);
     WV_GA unsigned short* ra = (WV_GA unsigned short*)rfl64(ws->ra);
     const unsigned n = (unsigned)kp.n;
     const unsigned nrounds = rflu(ws->nrounds);
@@ -527,8 +540,9 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         for (int i = 0; i < 8; ++i) {
             const unsigned idx = 64u * i + (unsigned)lane;
             const unsigned src = g0 + (idx < M ? idx : 0u);
-            v[i] = sv[src < n ? src : n - 1u];
-            tg[i] = st[src < n ? src : n - 1u];
+            const Rec rc = rec_load(rec + (src < n ? src : n - 1u));
+            v[i] = rc.v;
+            tg[i] = rc.t;
         }
     };
     if (nrounds > 0u) issue(0u);
@@ -638,8 +652,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                     else for (unsigned m2 = sb_; m2 < sl; ++m2) pos += (val[m2] == x) ? 1u : 0u;
                 }
                 if (need_ra) ra[tgv & 0xFFFFu] = (unsigned short)r2;
-                sv[pos] = x;
-                st[pos] = (tgv >> 16) & 0xFFu;
+                rec_store(rec + pos, x, (tgv >> 16) & 0xFFu);
             }
         }
         lds_fence();
@@ -690,10 +703,8 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
 // are set aside and counted exactly afterwards.  Sets ws->fallback when it cannot serve the slice.
 WV_PHASE void ph_fold(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
-    WV_LA double* fa = (WV_LA double*)(wb + OFF_FA);
-    WV_LA double* fb = (WV_LA double*)(wb + OFF_FB);
-    WV_LA unsigned char* sa = (WV_LA unsigned char*)(wb + OFF_SA);
-    WV_LA unsigned char* sb = (WV_LA unsigned char*)(wb + OFF_SB);
+    WV_LA double* fv = (WV_LA double*)(wb + OFF_FA);            // the tile's two pieces: A piece at 0, B piece at na + 2
+    WV_LA unsigned char* fs = (WV_LA unsigned char*)(wb + OFF_SA); // their split-chain slots
     WV_LA long long* facc = (WV_LA long long*)(wb + OFF_FACC);
     WV_LA unsigned long long* tor = (WV_LA unsigned long long*)(wb + OFF_TOR);
     WV_LA unsigned long long* tand = tor + WV_MAXM;
@@ -704,8 +715,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
     WV_LA unsigned char* tsl = (WV_LA unsigned char*)(wb + OFF_TSL);
     WV_LA double* mean_j = (WV_LA double*)(wb + OFF_MEAN);
     WV_LA double* var_j = mean_j + WV_MAXM;
-    const WV_GA double* sv = (const WV_GA double*)rfl64(ws->sv);
-    const WV_GA unsigned* st = (const WV_GA unsigned*)rfl64(ws->st);
+    const WV_GA Rec* rec = (const WV_GA Rec*)rfl64(ws->rec);
     typedef xs_of<T> ZT_t;
     const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab;
     const unsigned n = (unsigned)kp.n, niter = (unsigned)kp.niter;
@@ -718,15 +728,16 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
         const T d = (T)((T)x - medT);
         return (double)(d < (T)0 ? -d : d);
     };
+    auto S = [&](unsigned i) -> double { return rec[i].v; }; // the sorted slice
     const unsigned h = (n - 1u) / 2u;
-    int zero = 0;
+    unsigned zero = 0u;
     asm volatile("" : "+v"(zero));
-    const unsigned imed = rflu(((T)sv[h + zero] == medT) ? h : h + 1u);
+    const unsigned imed = rflu(((T)S(h + zero) == medT) ? h : h + 1u);
     bool ok;
     {
-        const double below = sv[(imed > 0u ? imed - 1u : 0u) + zero], at = sv[(imed < n ? imed : n - 1u) + zero];
+        const double below = S((imed > 0u ? imed - 1u : 0u) + zero), at = S((imed < n ? imed : n - 1u) + zero);
         ok = (imed == 0u || (T)below <= medT) && (imed == n || (T)at >= medT); // (equals of the median may sit on either side)
-        const double f0 = fold(sv[zero]), f1 = fold(sv[n - 1u + zero]);
+        const double f0 = fold(S(zero)), f1 = fold(S(n - 1u + zero));
         ok = ok && f0 < inf && f1 < inf; // (the +inf sentinels behind the runs must beat every member)
         ok = rfl(ok ? 1 : 0) != 0;
     }
@@ -738,32 +749,34 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
     if (lane == 0) *tln = 0u;
     if (ok) {
         // tb[k] = members of A among the first k FT merged outputs (A first on ties): A[mid] is among the first d outputs iff
-        // A[mid] <= B[d - mid - 1], monotone in mid
+        // A[mid] <= B[d - mid - 1], monotone in mid.  One lane per boundary, all boundaries at once.
         if ((unsigned)lane <= ntile) {
             const unsigned d = ((unsigned)lane * (unsigned)FT < n) ? (unsigned)lane * (unsigned)FT : n;
             unsigned lo = d > nB ? d - nB : 0u, hi = d < nA ? d : nA;
             while (lo < hi) {
                 const unsigned mid = (lo + hi) >> 1;
-                if (fold(sv[imed - 1u - mid]) <= fold(sv[imed + (d - mid - 1u)])) lo = mid + 1u; else hi = mid;
+                if (fold(S(imed - 1u - mid)) <= fold(S(imed + (d - mid - 1u)))) lo = mid + 1u; else hi = mid;
             }
             tb[lane] = lo;
         }
         lds_fence();
         const unsigned cp = (unsigned)lane & 7u;
-        // a tile's pieces: entry e = member e - 1 of the piece (the member in front of it, its na / nb members, the one behind)
-        double xa[5], xb[5];
-        unsigned la[5], lb[5];
+        // A tile's image: entry e < na + 2 = member a0 - 1 + e of A (the member in front of the piece, its na members, the one
+        // behind it), then the B piece likewise; -inf in front of a run, +inf behind it.  One record per entry; the next tile's
+        // records are in flight while this one is merged.
+        constexpr int NR = (FT + 4 + 63) / 64;
+        Rec rr[NR];
         auto issue = [&](unsigned k) {
-            const unsigned a0 = rflu(tb[k]), b0 = k * (unsigned)FT - a0;
+            const unsigned k0 = k * (unsigned)FT, cntk = (n - k0 < (unsigned)FT) ? n - k0 : (unsigned)FT;
+            const unsigned a0 = rflu(tb[k]), a1 = rflu(tb[k + 1u]), b0 = k0 - a0, qb = a1 - a0 + 2u;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int e = 64 * i + lane;
-                const long long ia = (long long)a0 + e - 1, ib = (long long)b0 + e - 1;
-                const bool va = e < FE && ia >= 0 && ia < (long long)nA, vb = e < FE && ib >= 0 && ib < (long long)nB;
-                const unsigned srcA = va ? (unsigned)((long long)imed - 1 - ia) : 0u;
-                const unsigned srcB = vb ? (unsigned)((long long)imed + ib) : 0u;
-                xa[i] = sv[srcA]; la[i] = st[srcA];
-                xb[i] = sv[srcB]; lb[i] = st[srcB];
+            for (int i = 0; i < NR; ++i) {
+                const unsigned e = 64u * (unsigned)i + (unsigned)lane;
+                const bool isA = e < qb;
+                const long long mem = isA ? (long long)a0 - 1 + e : (long long)b0 - 1 + (e - qb); // member of its run
+                const bool val_ = e < cntk + 4u && mem >= 0 && mem < (long long)(isA ? nA : nB);
+                const unsigned src = val_ ? (isA ? (unsigned)((long long)imed - 1 - mem) : (unsigned)((long long)imed + mem)) : 0u;
+                rr[i] = rec_load(rec + src);
             }
         };
         issue(0u);
@@ -771,17 +784,16 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
             const unsigned k0 = k * (unsigned)FT;
             const unsigned cntk = (n - k0 < (unsigned)FT) ? n - k0 : (unsigned)FT;
             const unsigned a0 = rflu(tb[k]), a1 = rflu(tb[k + 1u]), b0 = k0 - a0;
-            const unsigned na = a1 - a0, nb = cntk - na;
+            const unsigned na = a1 - a0, nb = cntk - na, qb = na + 2u;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int e = 64 * i + lane;
-                if (e < FE) {
-                    const long long ia = (long long)a0 + e - 1, ib = (long long)b0 + e - 1;
-                    const bool va = ia >= 0 && ia < (long long)nA, vb = ib >= 0 && ib < (long long)nB;
-                    fa[e] = va ? fold(xa[i]) : (e == 0 ? -inf : inf);
-                    fb[e] = vb ? fold(xb[i]) : (e == 0 ? -inf : inf);
-                    sa[e] = (unsigned char)la[i];
-                    sb[e] = (unsigned char)lb[i];
+            for (int i = 0; i < NR; ++i) {
+                const unsigned e = 64u * (unsigned)i + (unsigned)lane;
+                if (e < cntk + 4u) {
+                    const bool isA = e < qb;
+                    const long long mem = isA ? (long long)a0 - 1 + e : (long long)b0 - 1 + (e - qb);
+                    const bool val_ = mem >= 0 && mem < (long long)(isA ? nA : nB);
+                    fv[e] = val_ ? fold(rr[i].v) : (mem < 0 ? -inf : inf);
+                    fs[e] = (unsigned char)rr[i].t;
                 }
             }
             // the scores of this lane's four merged positions: position p has rank p + 1 unless it has equals
@@ -792,24 +804,25 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
             if (k + 1u < ntile) issue(k + 1u);
             lds_fence();
             if (d < cntk) {
-                // diagonal: members of the A piece among the first d outputs of the tile
+                // diagonal: members of the A piece among the first d outputs of the tile (A entry x at fv[x], B entry x at fv[qb + x])
                 unsigned lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
                 while (lo < hi) {
                     const unsigned mid = (lo + hi) >> 1;
-                    if (fa[1u + mid] <= fb[d - mid]) lo = mid + 1u; else hi = mid;
+                    if (fv[1u + mid] <= fv[qb + d - mid]) lo = mid + 1u; else hi = mid;
                 }
-                unsigned a = lo, b = d - lo;
-                const double pa = fa[a], pb = fb[b];
+                unsigned a = lo, b = qb + (d - lo); // indices of the entries in front of the two heads
+                const double pa = fv[a], pb = fv[b];
                 double prev = pa > pb ? pa : pb;
-                double ca = fa[1u + a], cb = fb[1u + b];
+                double ca = fv[1u + a], cb = fv[1u + b];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const bool ta = ca <= cb;
                     const double cur = ta ? ca : cb;
-                    const unsigned slot = ta ? (unsigned)sa[1u + a] : (unsigned)sb[1u + b];
+                    const unsigned is = ta ? 1u + a : 1u + b;
+                    const unsigned slot = (unsigned)fs[is];
                     a += ta ? 1u : 0u;
                     b += ta ? 0u : 1u;
-                    const double nx = ta ? fa[1u + a] : fb[1u + b];
+                    const double nx = fv[is + 1u];
                     ca = ta ? nx : ca;
                     cb = ta ? cb : nx;
                     const double nxt = ca < cb ? ca : cb;
@@ -838,7 +851,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
             unsigned lo = 0u, hi = arun ? nA : nB;
             while (lo < hi) {
                 const unsigned mid = (lo + hi) >> 1;
-                const double x = fold(arun ? sv[imed - 1u - mid] : sv[imed + mid]);
+                const double x = fold(arun ? S(imed - 1u - mid) : S(imed + mid));
                 if (le ? (x <= f) : (x < f)) lo = mid + 1u; else hi = mid;
             }
             return lo;
@@ -1276,8 +1289,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
     WV_LA WS* ws = (WV_LA WS*)(wb + OFF_WS);
     if (lane == 0) {
         ws->kp = (unsigned long long)kpp;
-        ws->sv = (unsigned long long)(wa.sv + (long long)gw * wa.npad);
-        ws->st = (unsigned long long)(wa.st + (long long)gw * wa.npad);
+        ws->rec = (unsigned long long)(wa.rec + (long long)gw * wa.npad);
         ws->ra = (unsigned long long)(wa.ra + (long long)gw * wa.npad);
         ws->dbg = (unsigned long long)wa.dbg;
         ws->lz = smem0;
@@ -1381,8 +1393,7 @@ void set_debug_buf(unsigned* p) { g_debug_buf = p; }
 void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgroups, void* scratch, unsigned* fb_list, int* fb_count) {
     const long long waves_total = (long long)workgroups * g.waves;
     WvArgs wa;
-    wa.sv = (double*)scratch;
-    wa.st = (unsigned*)((char*)scratch + (size_t)waves_total * g.npad * 8);
+    wa.rec = (Rec*)scratch;
     wa.ra = (unsigned short*)((char*)scratch + (size_t)waves_total * g.npad * 12);
     wa.fb_list = fb_list;
     wa.fb_count = fb_count;
