@@ -44,7 +44,7 @@ constexpr int NCLS = 128;          // classes: #{splitters <= x}
 constexpr int WR = 512;            // members of a round (the LDS image)
 constexpr int NBIN = 512;          // fine bins of a round
 constexpr int MAXROUNDS = 64;
-constexpr int FT = 256;            // merged outputs of a fold tile (4 per lane)
+constexpr int FT = 512;            // merged outputs of a fold tile (8 per lane)
 constexpr int WTCAP = 64;          // folded members with equals kept for the exact pass
 constexpr int ZT = 3;              // Hankel tiles per sweep: 32 lags
 constexpr int STG = 64 * ((WV_NITER + 63) / 64) + 272; // doubles of the time-order stage: chain + zero halo for the last tile's shifted operand
@@ -58,7 +58,9 @@ constexpr int OFF_CCUR = OFF_IW + 128 * 8;             // unsigned ccur[128]: cl
 constexpr int OFF_RTAB = OFF_CCUR + 128 * 4;           // unsigned short rtab[MAXROUNDS + 2]: first class of every round
 constexpr int OFF_OST = ((OFF_RTAB + (MAXROUNDS + 2) * 2 + 7) / 8) * 8; // double ostat[8]
 constexpr int OFF_ORK = OFF_OST + 8 * 8;               // unsigned orank[8]: doubled tied rank of every captured order statistic
-constexpr int OFF_MEAN = OFF_ORK + 8 * 4;              // double mean_j[16], var_j[16], mu_j[16]
+constexpr int OFF_LCUR = OFF_ORK + 8 * 4;              // unsigned lcur[16]: fill of every split chain's rank list
+constexpr int OFF_JBASE = OFF_LCUR + WV_MAXM * 4;      // unsigned short jbase[16]: pooled index of every split chain's first draw
+constexpr int OFF_MEAN = OFF_JBASE + WV_MAXM * 2;      // double mean_j[16], var_j[16], mu_j[16]
 constexpr int OFF_WS = OFF_MEAN + 3 * WV_MAXM * 8;     // struct WS: what the phases of a parameter hand to each other (wave-uniform)
 constexpr int WS_BYTES = 192;
 constexpr int OFF_PROF = OFF_WS + WS_BYTES;            // (diagnostics build WV_PROF) unsigned long long prof[16]: cycles per phase
@@ -71,8 +73,8 @@ static_assert(OFF_LAGA + 256 * 8 <= OFF_CCUR, "lag table lives over the splitter
 // rank view
 constexpr int OFF_VAL = OFF_VIEW;                      // double val[WR]; during passes A / B: uint8 cls[WV_MAXN]
 constexpr int OFF_TAG = OFF_VAL + WR * 8;              // unsigned tag[WR]
-constexpr int OFF_BIN = OFF_TAG + WR * 4;              // unsigned short binid[WR]
-constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors
+constexpr int OFF_SMASK = OFF_TAG + WR * 4;            // uint64 smask[WR / 64 + 1]: bit s = slot s is the first of its bin (+ a sentinel bit behind the last slot); rmask[WR / 64]: slot s sits in a reserved bin
+constexpr int OFF_CNT = OFF_SMASK + (2 * (WR / 64) + 1) * 8; // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
 static_assert(WV_MAXN <= WR * 8, "the time-order class bytes of passes A / B live in the image");
 // fold view
@@ -121,7 +123,7 @@ __device__ __forceinline__ Rec rec_load(const __attribute__((address_space(1))) 
 }
 struct WvArgs {
     Rec* rec;              // [waves][npad]: the slice class-sorted, then (in place, round by round) sorted
-    unsigned short* ra;    // [waves][npad]: doubled tied rank of every element, time order
+    unsigned* ra;          // [waves][npad]: per split chain the list of (draw | doubled tied rank << 16) of its members, in the order the rounds rank them
     unsigned* fb_list;     // parameters left to the general kernel
     int* fb_count;
     long long npad;
@@ -505,11 +507,14 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     WV_LA unsigned* orank = (WV_LA unsigned*)(wb + OFF_ORK);
     WV_LA double* val = (WV_LA double*)(wb + OFF_VAL);
     WV_LA unsigned* tagl = (WV_LA unsigned*)(wb + OFF_TAG);
-    WV_LA unsigned short* binid = (WV_LA unsigned short*)(wb + OFF_BIN);
+    WV_LA unsigned long long* smask = (WV_LA unsigned long long*)(wb + OFF_SMASK);
+    WV_LA unsigned long long* rmask = smask + (WR / 64 + 1);
     WV_LA unsigned* cnt = (WV_LA unsigned*)(wb + OFF_CNT);
     WV_GA Rec* rec = (WV_GA Rec*)rfl64(ws->rec);
-    WV_GA unsigned short* ra = (WV_GA unsigned short*)rfl64(ws->ra);
-    const unsigned n = (unsigned)kp.n;
+    WV_GA unsigned* rl = (WV_GA unsigned*)rfl64(ws->ra);
+    WV_LA unsigned* lcur = (WV_LA unsigned*)(wb + OFF_LCUR);
+    WV_LA unsigned short* jbase = (WV_LA unsigned short*)(wb + OFF_JBASE);
+    const unsigned n = (unsigned)kp.n, niter = (unsigned)kp.niter;
     const unsigned nrounds = rflu(ws->nrounds);
     const bool need_med = kp.need_rt != 0;
     const bool need_q = kp.need_et && kp.ess_ok;
@@ -522,6 +527,12 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         else if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; ntgt = 2; }
         else if (need_q) { tp[0] = ql0; tp[1] = ql1; tp[2] = qh0; tp[3] = qh1; ntgt = 4; }
     }
+    if (lane < WV_MAXM) { // per split chain: fill of its rank list; pooled index of its first draw (src/utils.jl:29-36)
+        const unsigned s_ = (unsigned)kp.s, rem_ = (unsigned)kp.rem, c = (unsigned)lane / s_, k = (unsigned)lane - c * s_;
+        lcur[lane] = 0u;
+        jbase[lane] = (unsigned short)(c * (unsigned)kp.D + k * niter + (k < rem_ ? k : rem_));
+    }
+    lds_fence();
     unsigned anyodd = 0u;
     // members of round r: one contiguous piece [g0, g1) of the class-sorted scratch; the next round's loads are issued as soon
     // as this round's members sit in the LDS image (their registers are free then)
@@ -555,6 +566,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         const double fsub = (double)((1u << sh) - 1u), fcap = (double)((1u << sh) - 2u);
 #pragma unroll
         for (int q = 0; q < NBIN / 2 / 64; ++q) cnt[lane + 64 * q] = 0u;
+        if (lane < 2 * (WR / 64) + 1) smask[lane] = 0ull;
         unsigned bn[8];
         {
             double lo[8], wd[8];
@@ -586,6 +598,12 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             const unsigned incl = wave_incl_scan_u32(tot), bb = incl - tot;
 #pragma unroll
             for (int q = 0; q < 4; ++q) cnt[4 * lane + q] = (bb + s8[2 * q]) | ((bb + s8[2 * q + 1]) << 16);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { // the first slot of every bin that has members
+                const unsigned c8 = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu, ps = bb + s8[q];
+                if (c8) lds_or(&smask[ps >> 6], 1ull << (ps & 63u));
+            }
+            if (lane == 0) lds_or(&smask[M >> 6], 1ull << (M & 63u)); // (the bin behind the last one)
         }
         lds_fence();
         WPROF(11);
@@ -596,7 +614,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                 const unsigned pos = (lds_add(&cnt[b >> 1], 1u << shb) >> shb) & 0xFFFFu;
                 val[pos] = v[i];
                 tagl[pos] = tg[i];
-                binid[pos] = (unsigned short)bn[i];
+                if (bn[i] >> 15) lds_or(&rmask[pos >> 6], 1ull << (pos & 63u));
             }
         }
         if (r + 1u < nrounds) issue(r + 1u);
@@ -605,38 +623,57 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         bool tin = false; // any target order statistic in this round?
 #pragma unroll
         for (int t = 0; t < 6; ++t) tin = tin || (t < ntgt && tp[t] >= g0 && tp[t] < g1);
-        // dense count in slot order: tied rank, place in sorted order
-        for (unsigned i = 0; 64u * i < M; ++i) {
-            const unsigned sl = 64u * i + (unsigned)lane;
-            if (sl < M) {
+        // dense count in slot order: tied rank, place in sorted order.  The image is sorted by bin; the start bits give every slot
+        // the bounds [st, en) of its bin without a read (bit scans on wave-uniform words), so a slot's mates -- about one -- arrive
+        // in the same LDS round trip as its own value; a reserved bin (all members equal: a point mass) needs no compare at all.
+        unsigned long long sw[WR / 64 + 1], rw[WR / 64];
+#pragma unroll
+        for (int q = 0; q < WR / 64 + 1; ++q) sw[q] = rfl64(smask[q]);
+#pragma unroll
+        for (int q = 0; q < WR / 64; ++q) rw[q] = rfl64(rmask[q]);
+        unsigned nxt[WR / 64]; // first start bit behind word q
+        {
+            unsigned run = M;
+#pragma unroll
+            for (int q = WR / 64; q >= 1; --q) {
+                if (sw[q]) run = 64u * (unsigned)q + (unsigned)__builtin_ctzll(sw[q]);
+                nxt[q - 1] = run;
+            }
+        }
+        unsigned lastpos = 0u; // last start bit in front of word i
+#pragma unroll
+        for (int i = 0; i < WR / 64; ++i) {
+            const unsigned sl = 64u * (unsigned)i + (unsigned)lane;
+            if (64u * (unsigned)i < M && sl < M) {
+                const unsigned long long wc = sw[i];
+                const unsigned long long below = wc & (~0ull >> (63 - lane));
+                const unsigned long long above = (lane < 63) ? (wc & (~0ull << (lane + 1))) : 0ull;
+                const unsigned st_ = below ? 64u * (unsigned)i + 63u - (unsigned)__builtin_clzll(below) : lastpos;
+                const unsigned en = above ? 64u * (unsigned)i + (unsigned)__builtin_ctzll(above) : nxt[i];
                 const double x = val[sl];
                 const unsigned tgv = tagl[sl];
-                const unsigned bb = binid[sl], b = bb & 0x7FFFu, bm = b > 0u ? b - 1u : 0u;
-                const unsigned wa_ = cnt[b >> 1], wb_ = cnt[bm >> 1];
-                const unsigned en = (b & 1u) ? wa_ >> 16 : wa_ & 0xFFFFu;
-                const unsigned sb_ = (b == 0u) ? 0u : ((bm & 1u) ? wb_ >> 16 : wb_ & 0xFFFFu);
-                const bool rsv = (bb >> 15) != 0u;
-                unsigned less = sb_, eq;
-                if (rsv) {
-                    eq = en - sb_;
+                unsigned less, eq, eql = 0u; // members of the round below x; equal to x (x included); equal to x in front of its slot
+                if ((rw[i] >> lane) & 1ull) {
+                    less = st_;
+                    eq = en - st_;
+                    eql = sl - st_;
                 } else {
-                    eq = 0u;
-                    const unsigned last = en - 1u;
-                    for (unsigned m2 = sb_; m2 <= last; m2 += 4u) {
-                        const unsigned i1 = m2 + 1u, i2 = m2 + 2u, i3 = m2 + 3u;
-                        const double y0 = val[m2];
-                        const double y1 = val[i1 <= last ? i1 : last];
-                        const double y2 = val[i2 <= last ? i2 : last];
-                        const double y3 = val[i3 <= last ? i3 : last];
-                        less += (y0 < x) ? 1u : 0u;
-                        eq += (y0 == x) ? 1u : 0u;
-                        less += (i1 <= last && y1 < x) ? 1u : 0u;
-                        eq += (i1 <= last && y1 == x) ? 1u : 0u;
-                        less += (i2 <= last && y2 < x) ? 1u : 0u;
-                        eq += (i2 <= last && y2 == x) ? 1u : 0u;
-                        less += (i3 <= last && y3 < x) ? 1u : 0u;
-                        eq += (i3 <= last && y3 == x) ? 1u : 0u;
+                    unsigned lt = 0u, eqa = 0u;
+                    for (unsigned k0 = st_; k0 < en; k0 += 4u) {
+                        double y[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { const unsigned k = k0 + (unsigned)j; y[j] = val[k < en ? k : en - 1u]; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned k = k0 + (unsigned)j;
+                            const bool in = k < en;
+                            lt += (in && y[j] < x) ? 1u : 0u;
+                            eqa += (in && y[j] == x) ? 1u : 0u;
+                            eql += (in && k < sl && y[j] == x) ? 1u : 0u;
+                        }
                     }
+                    less = st_ + lt;
+                    eq = eqa;
                 }
                 const unsigned gl = g0 + less;
                 const unsigned r2 = 2u * gl + eq + 1u; // doubled tied rank: first + last place of the run of equals, 1-based
@@ -646,14 +683,20 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                     for (int t = 0; t < 6; ++t)
                         if (t < ntgt && tp[t] - gl < eq) { ostat[t] = x; orank[t] = r2; }
                 }
-                unsigned pos = gl;
-                if (eq != 1u) {
-                    if (rsv) pos += sl - sb_;
-                    else for (unsigned m2 = sb_; m2 < sl; ++m2) pos += (val[m2] == x) ? 1u : 0u;
+                const unsigned pos = gl + eql; // equals take the places of their run in slot order
+                if (need_ra) {
+                    // the rank goes to the list of its split chain (draw inside the chain | doubled rank << 16): lanes of one chain
+                    // draw neighbouring places, so the store fills cache lines -- a 2-byte scatter to the time position cost one
+                    // request per lane, 13 % of the kernel; the series phase puts the list in time order in LDS
+                    const unsigned slot = (tgv >> 16) & 0xFFu;
+                    if (slot != 255u) {
+                        const unsigned ps = lds_add(&lcur[slot], 1u);
+                        rl[slot * niter + ps] = (r2 << 16) | ((tgv & 0xFFFFu) - (unsigned)jbase[slot]);
+                    }
                 }
-                if (need_ra) ra[tgv & 0xFFFFu] = (unsigned short)r2;
                 rec_store(rec + pos, x, (tgv >> 16) & 0xFFu);
             }
+            if (sw[i]) lastpos = 64u * (unsigned)i + 63u - (unsigned)__builtin_clzll(sw[i]);
         }
         lds_fence();
         WPROF(13);
@@ -796,11 +839,12 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
                     fs[e] = (unsigned char)rr[i].t;
                 }
             }
-            // the scores of this lane's four merged positions: position p has rank p + 1 unless it has equals
-            const unsigned d = 4u * (unsigned)lane;
-            double zq[4];
+            // the scores of this lane's merged positions: position p has rank p + 1 unless it has equals
+            constexpr int EPL = FT / 64;
+            const unsigned d = (unsigned)EPL * (unsigned)lane;
+            double zq[EPL];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { const unsigned pp = k0 + d + (unsigned)i; zq[i] = (double)gzd[(pp < n ? pp : n - 1u) + 1u]; }
+            for (int i = 0; i < EPL; ++i) { const unsigned pp = k0 + d + (unsigned)i; zq[i] = (double)gzd[(pp < n ? pp : n - 1u) + 1u]; }
             if (k + 1u < ntile) issue(k + 1u);
             lds_fence();
             if (d < cntk) {
@@ -815,7 +859,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
                 double prev = pa > pb ? pa : pb;
                 double ca = fv[1u + a], cb = fv[1u + b];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < EPL; ++i) {
                     const bool ta = ca <= cb;
                     const double cur = ta ? ca : cb;
                     const unsigned is = ta ? 1u + a : 1u + b;
@@ -906,9 +950,8 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
     typedef xs_of<T> ZT_t;
     const WV_LA ZT_t* lz = (const WV_LA ZT_t*)(unsigned long long)rflu(ws->lz);
     const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab;
-    const WV_GA unsigned short* ra = (const WV_GA unsigned short*)rfl64(ws->ra);
-    const unsigned D = (unsigned)kp.D;
-    const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
+    const WV_GA unsigned* rl = (const WV_GA unsigned*)rfl64(ws->ra);
+    const unsigned niter = (unsigned)kp.niter;
     const int m = kp.m;
     const long long maxlag = kp.maxlag;
     const double nan = __builtin_nan(""), dn = (double)niter, dm = (double)m;
@@ -917,7 +960,6 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
     const bool anyodd = rflu(ws->anyodd) != 0u;
     const unsigned nblk = (niter + 63u) >> 6;
     const int c_hi = 16 * ((int)maxlag / 16 + 1);
-    auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); };
     // indicator words behind the stage, when both fit the view
     const int nwS = (int)nblk, nwU = nwS + (int)(maxlag >> 6) + 2;
     const unsigned stg_doubles = 64u * nblk + 272u;
@@ -935,15 +977,15 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
     int block = 0;
     constexpr int NB = (WV_NITER + 63) / 64;
     unsigned rn[NB];
-    auto issue = [&](int j) { // the ranks of split chain j: all its rows in flight
-        const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
-        const WV_GA unsigned short* rj = ra + (c * D + row0(k));
+    auto issue = [&](int j) { // the rank list of split chain j: all its rows in flight
+        const WV_GA unsigned* rj = rl + (unsigned)j * niter;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             const unsigned t = 64u * (unsigned)b + (unsigned)lane;
             rn[b] = rj[t < niter ? t : niter - 1u];
         }
     };
+    WV_LA unsigned short* rank_t = (WV_LA unsigned short*)stage; // the list in time order (in the bytes of the stage, before the chain is staged)
     while (true) {
         long long kend = k0 + 16 * (ZT - 1);
         if (kend > maxlag + 1) kend = maxlag + 1;
@@ -958,8 +1000,15 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
         for (int j = 0; j < m; ++j) {
             unsigned r2[NB];
 #pragma unroll
-            for (int b = 0; b < NB; ++b) r2[b] = rn[b];
+            for (int b = 0; b < NB; ++b) { // list -> time order: (draw, rank) pairs scattered in LDS, read back by position
+                const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                if ((unsigned)b < nblk && t < niter) rank_t[rn[b] & 0xFFFFu] = (unsigned short)(rn[b] >> 16);
+            }
             if (j + 1 < m) issue(j + 1);
+            lds_fence();
+#pragma unroll
+            for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rank_t[t < niter ? t : niter - 1u]; }
+            lds_fence();
             double K = 0.0;
             long long a1 = 0, a2 = 0;
             const double mu0 = (block > 0) ? mu_j[j] : 0.0;
@@ -971,38 +1020,38 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
                 for (int b = 0; b < NB; ++b) if (r2[b] & 1u) z[b] = (double)gz[r2[b]];
             }
             K = readlane_d(z[0], 0);
+            double mu = mu0;
+            if (block == 0) {
+                // exact integer sums of the shifted scores; the expressions of series_z_phase: bit-identical means and variances
 #pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                if ((unsigned)b < nblk) {
+                for (int b = 0; b < NB; ++b) {
                     const unsigned t = 64u * (unsigned)b + (unsigned)lane;
-                    const bool okt = t < niter;
-                    const double u = okt ? z[b] - K : 0.0;
-                    if (block == 0) {
-                        a1 += okt ? fx.u(u) : 0;
-                        a2 += okt ? fx.uu(u * u) : 0;
-                        stage[t] = u;
-                        if (bits) {
+                    const bool okt = (unsigned)b < nblk && t < niter;
+                    const double u = z[b] - K;
+                    a1 += okt ? fx.u(u) : 0;
+                    a2 += okt ? fx.uu(u * u) : 0;
+                }
+                const double S1 = (double)wave_sum_i64(a1) * fx.i1, S2 = (double)wave_sum_i64(a2) * fx.i2;
+                mu = S1 / dn;
+                const double Cc = S2 - mu * S1;
+                if (lane == 0) { var_j[j] = Cc / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
+                if (bits) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if ((unsigned)b < nblk) {
+                            const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
                             const unsigned long long q0 = __ballot(okt && r2[b] <= r2q0), q1 = __ballot(okt && r2[b] <= r2q1);
                             if (lane == 0) { sb2[(2 * j) * nwU + b] = q0; sb2[(2 * j + 1) * nwU + b] = q1; }
                             __builtin_amdgcn_wave_barrier();
                         }
-                    } else {
-                        stage[t] = okt ? u - mu0 : 0.0;
                     }
                 }
             }
-            if (block == 0) {
-                const double S1 = (double)wave_sum_i64(a1) * fx.i1, S2 = (double)wave_sum_i64(a2) * fx.i2;
-                const double mu = S1 / dn;
-                const double Cc = S2 - mu * S1;
-                if (lane == 0) { var_j[j] = Cc / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
-                if (acov) {
-                    lds_fence();
+            if (acov) { // the centred chain, zeros behind it
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
-                        const unsigned t = 64u * (unsigned)b + (unsigned)lane;
-                        if ((unsigned)b < nblk && t < niter) stage[t] -= mu;
-                    }
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                    if ((unsigned)b < nblk) stage[t] = (t < niter) ? (z[b] - K) - mu : 0.0;
                 }
             }
             WPROF(14);
@@ -1093,8 +1142,7 @@ WV_PHASE void ph_indicators(unsigned wbase_arg) {
     WV_LA double* icov = (WV_LA double*)(wb + OFF_ICOV);
     WV_LA double* imean = (WV_LA double*)(wb + OFF_IMEAN);
     const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
-    const WV_GA unsigned short* ra = (const WV_GA unsigned short*)rfl64(ws->ra);
-    const unsigned D = (unsigned)kp.D;
+    const WV_GA unsigned* rl = (const WV_GA unsigned*)rfl64(ws->ra);
     const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
     const int m = kp.m;
     const long long cs = kp.cstride, maxlag = kp.maxlag;
@@ -1126,10 +1174,17 @@ WV_PHASE void ph_indicators(unsigned wbase_arg) {
             const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
             unsigned long long q0[NB], q1[NB];
             if (byrank) {
-                const WV_GA unsigned short* rj = ra + (c * D + row0(k));
-                unsigned r2[NB];
+                const WV_GA unsigned* rj = rl + (unsigned)j * niter;
+                WV_LA unsigned short* rank_t = (WV_LA unsigned short*)icov; // (the list in time order, in the bytes of the lag table that is zeroed below)
+                unsigned pr[NB], r2[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rj[t < niter ? t : niter - 1u]; }
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; pr[b] = rj[t < niter ? t : niter - 1u]; }
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; if (t < niter) rank_t[pr[b] & 0xFFFFu] = (unsigned short)(pr[b] >> 16); }
+                lds_fence();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rank_t[t < niter ? t : niter - 1u]; }
+                lds_fence();
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
@@ -1376,7 +1431,7 @@ Geo geometry(long long n, int f32) {
 }
 
 size_t scratch_bytes(const Geo& g, long long waves_total) {
-    return (size_t)waves_total * (size_t)g.npad * (8 + 4 + 2);
+    return (size_t)waves_total * (size_t)g.npad * (12 + 4);
 }
 
 int prepare_device() { // > 64 KB of dynamic LDS needs the opt-in, per kernel and device (called by mdt_ctx_create on its device)
@@ -1394,7 +1449,7 @@ void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgr
     const long long waves_total = (long long)workgroups * g.waves;
     WvArgs wa;
     wa.rec = (Rec*)scratch;
-    wa.ra = (unsigned short*)((char*)scratch + (size_t)waves_total * g.npad * 12);
+    wa.ra = (unsigned*)((char*)scratch + (size_t)waves_total * g.npad * 12);
     wa.fb_list = fb_list;
     wa.fb_count = fb_count;
     wa.npad = g.npad;
