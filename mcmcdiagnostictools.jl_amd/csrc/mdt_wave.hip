@@ -65,7 +65,7 @@ constexpr int OFF_WS = OFF_MEAN + 3 * WV_MAXM * 8;     // struct WS: what the ph
 constexpr int WS_BYTES = 192;
 constexpr int OFF_PROF = OFF_WS + WS_BYTES;            // (diagnostics build WV_PROF) unsigned long long prof[16]: cycles per phase
 #ifdef WV_PROF
-constexpr int OFF_VIEW = ((OFF_PROF + 17 * 8 + 15) / 16) * 16;
+constexpr int OFF_VIEW = ((OFF_PROF + 25 * 8 + 15) / 16) * 16;
 #else
 constexpr int OFF_VIEW = ((OFF_PROF + 15) / 16) * 16;
 #endif
@@ -73,8 +73,8 @@ static_assert(OFF_LAGA + 256 * 8 <= OFF_CCUR, "lag table lives over the splitter
 // rank view
 constexpr int OFF_VAL = OFF_VIEW;                      // double val[WR]; during passes A / B: uint8 cls[WV_MAXN]
 constexpr int OFF_TAG = OFF_VAL + WR * 8;              // unsigned tag[WR]
-constexpr int OFF_SMASK = OFF_TAG + WR * 4;            // uint64 smask[WR / 64 + 1]: bit s = slot s is the first of its bin (+ a sentinel bit behind the last slot); rmask[WR / 64]: slot s sits in a reserved bin
-constexpr int OFF_CNT = OFF_SMASK + (2 * (WR / 64) + 1) * 8; // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors
+constexpr int OFF_BIN = OFF_TAG + WR * 4;              // unsigned short binid[WR]: bin of every slot | reserved-bin flag << 15
+constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors (read as 16-bit entries: the end of every bin)
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
 static_assert(WV_MAXN <= WR * 8, "the time-order class bytes of passes A / B live in the image");
 // fold view
@@ -284,7 +284,7 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
     const int lane = (int)(threadIdx.x & 63u);                                                       \
     (void)lane; (void)kp
 #ifdef WV_PROF
-#define WPROF(slot) do { if (lane == 0) { WV_LA unsigned long long* pr_ = (WV_LA unsigned long long*)(wb + OFF_PROF); const unsigned long long t_ = (unsigned long long)__builtin_readcyclecounter(); pr_[slot] += t_ - pr_[16]; pr_[16] = t_; } __builtin_amdgcn_wave_barrier(); } while (0)
+#define WPROF(slot) do { if (lane == 0) { WV_LA unsigned long long* pr_ = (WV_LA unsigned long long*)(wb + OFF_PROF); const unsigned long long t_ = (unsigned long long)__builtin_readcyclecounter(); pr_[slot] += t_ - pr_[24]; pr_[24] = t_; } __builtin_amdgcn_wave_barrier(); } while (0)
 #else
 #define WPROF(slot) do { } while (0)
 #endif
@@ -507,8 +507,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     WV_LA unsigned* orank = (WV_LA unsigned*)(wb + OFF_ORK);
     WV_LA double* val = (WV_LA double*)(wb + OFF_VAL);
     WV_LA unsigned* tagl = (WV_LA unsigned*)(wb + OFF_TAG);
-    WV_LA unsigned long long* smask = (WV_LA unsigned long long*)(wb + OFF_SMASK);
-    WV_LA unsigned long long* rmask = smask + (WR / 64 + 1);
+    WV_LA unsigned short* binid = (WV_LA unsigned short*)(wb + OFF_BIN);
     WV_LA unsigned* cnt = (WV_LA unsigned*)(wb + OFF_CNT);
     WV_GA Rec* rec = (WV_GA Rec*)rfl64(ws->rec);
     WV_GA unsigned* rl = (WV_GA unsigned*)rfl64(ws->ra);
@@ -566,7 +565,6 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         const double fsub = (double)((1u << sh) - 1u), fcap = (double)((1u << sh) - 2u);
 #pragma unroll
         for (int q = 0; q < NBIN / 2 / 64; ++q) cnt[lane + 64 * q] = 0u;
-        if (lane < 2 * (WR / 64) + 1) smask[lane] = 0ull;
         unsigned bn[8];
         {
             double lo[8], wd[8];
@@ -598,12 +596,6 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             const unsigned incl = wave_incl_scan_u32(tot), bb = incl - tot;
 #pragma unroll
             for (int q = 0; q < 4; ++q) cnt[4 * lane + q] = (bb + s8[2 * q]) | ((bb + s8[2 * q + 1]) << 16);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { // the first slot of every bin that has members
-                const unsigned c8 = (wv[q >> 1] >> ((q & 1) << 4)) & 0xFFFFu, ps = bb + s8[q];
-                if (c8) lds_or(&smask[ps >> 6], 1ull << (ps & 63u));
-            }
-            if (lane == 0) lds_or(&smask[M >> 6], 1ull << (M & 63u)); // (the bin behind the last one)
         }
         lds_fence();
         WPROF(11);
@@ -614,7 +606,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                 const unsigned pos = (lds_add(&cnt[b >> 1], 1u << shb) >> shb) & 0xFFFFu;
                 val[pos] = v[i];
                 tagl[pos] = tg[i];
-                if (bn[i] >> 15) lds_or(&rmask[pos >> 6], 1ull << (pos & 63u));
+                binid[pos] = (unsigned short)bn[i];
             }
         }
         if (r + 1u < nrounds) issue(r + 1u);
@@ -623,37 +615,21 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         bool tin = false; // any target order statistic in this round?
 #pragma unroll
         for (int t = 0; t < 6; ++t) tin = tin || (t < ntgt && tp[t] >= g0 && tp[t] < g1);
-        // dense count in slot order: tied rank, place in sorted order.  The image is sorted by bin; the start bits give every slot
-        // the bounds [st, en) of its bin without a read (bit scans on wave-uniform words), so a slot's mates -- about one -- arrive
-        // in the same LDS round trip as its own value; a reserved bin (all members equal: a point mass) needs no compare at all.
-        unsigned long long sw[WR / 64 + 1], rw[WR / 64];
-#pragma unroll
-        for (int q = 0; q < WR / 64 + 1; ++q) sw[q] = rfl64(smask[q]);
-#pragma unroll
-        for (int q = 0; q < WR / 64; ++q) rw[q] = rfl64(rmask[q]);
-        unsigned nxt[WR / 64]; // first start bit behind word q
-        {
-            unsigned run = M;
-#pragma unroll
-            for (int q = WR / 64; q >= 1; --q) {
-                if (sw[q]) run = 64u * (unsigned)q + (unsigned)__builtin_ctzll(sw[q]);
-                nxt[q - 1] = run;
-            }
-        }
-        unsigned lastpos = 0u; // last start bit in front of word i
-#pragma unroll
-        for (int i = 0; i < WR / 64; ++i) {
-            const unsigned sl = 64u * (unsigned)i + (unsigned)lane;
-            if (64u * (unsigned)i < M && sl < M) {
-                const unsigned long long wc = sw[i];
-                const unsigned long long below = wc & (~0ull >> (63 - lane));
-                const unsigned long long above = (lane < 63) ? (wc & (~0ull << (lane + 1))) : 0ull;
-                const unsigned st_ = below ? 64u * (unsigned)i + 63u - (unsigned)__builtin_clzll(below) : lastpos;
-                const unsigned en = above ? 64u * (unsigned)i + (unsigned)__builtin_ctzll(above) : nxt[i];
+        // dense count in slot order: tied rank, place in sorted order.  The image is sorted by bin; after the placement the packed
+        // cursors, read as 16-bit entries, are the END of every bin (and the start of the next one): a slot takes the bounds of
+        // its bin from there and compares against the bin's members -- about one -- four at a time; a reserved bin (all members
+        // equal: a point mass) needs no compare.  (A version that derived the bounds from start-bit masks with no second round
+        // trip to LDS was tried: 64-bit bit scans per lane made it 25 % slower -- this loop is bound by instruction issue.)
+        const WV_LA unsigned short* cend = (const WV_LA unsigned short*)cnt;
+        for (unsigned i = 0; 64u * i < M; ++i) {
+            const unsigned sl = 64u * i + (unsigned)lane;
+            if (sl < M) {
                 const double x = val[sl];
                 const unsigned tgv = tagl[sl];
+                const unsigned bb = binid[sl], b = bb & 0x7FFFu;
+                const unsigned en = cend[b], st_ = b ? (unsigned)cend[b - 1u] : 0u;
                 unsigned less, eq, eql = 0u; // members of the round below x; equal to x (x included); equal to x in front of its slot
-                if ((rw[i] >> lane) & 1ull) {
+                if (bb >> 15) {
                     less = st_;
                     eq = en - st_;
                     eql = sl - st_;
@@ -696,7 +672,6 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                 }
                 rec_store(rec + pos, x, (tgv >> 16) & 0xFFu);
             }
-            if (sw[i]) lastpos = 64u * (unsigned)i + 63u - (unsigned)__builtin_clzll(sw[i]);
         }
         lds_fence();
         WPROF(13);
@@ -803,6 +778,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
             tb[lane] = lo;
         }
         lds_fence();
+        WPROF(17);
         const unsigned cp = (unsigned)lane & 7u;
         // A tile's image: entry e < na + 2 = member a0 - 1 + e of A (the member in front of the piece, its na members, the one
         // behind it), then the B piece likewise; -inf in front of a run, +inf behind it.  One record per entry; the next tile's
@@ -847,6 +823,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
             for (int i = 0; i < EPL; ++i) { const unsigned pp = k0 + d + (unsigned)i; zq[i] = (double)gzd[(pp < n ? pp : n - 1u) + 1u]; }
             if (k + 1u < ntile) issue(k + 1u);
             lds_fence();
+            WPROF(18);
             if (d < cntk) {
                 // diagonal: members of the A piece among the first d outputs of the tile (A entry x at fv[x], B entry x at fv[qb + x])
                 unsigned lo = d > nb ? d - nb : 0u, hi = d < na ? d : na;
@@ -854,6 +831,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
                     const unsigned mid = (lo + hi) >> 1;
                     if (fv[1u + mid] <= fv[qb + d - mid]) lo = mid + 1u; else hi = mid;
                 }
+                WPROF(19);
                 unsigned a = lo, b = qb + (d - lo); // indices of the entries in front of the two heads
                 const double pa = fv[a], pb = fv[b];
                 double prev = pa > pb ? pa : pb;
@@ -884,6 +862,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
                 }
             }
             lds_fence(); // (the next tile's staging stores come after every read of this tile's image)
+            WPROF(20);
         }
     }
     unsigned nt = 0u;
@@ -1352,8 +1331,8 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         ws->stop = wa.stop;
     }
 #ifdef WV_PROF
-    if (lane < 16) ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane] = 0ull;
-    if (lane == 0) ((WV_LA unsigned long long*)(wb + OFF_PROF))[16] = (unsigned long long)__builtin_readcyclecounter();
+    if (lane < 24) ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane] = 0ull;
+    if (lane == 0) ((WV_LA unsigned long long*)(wb + OFF_PROF))[24] = (unsigned long long)__builtin_readcyclecounter();
 #endif
     lds_fence();
 
@@ -1412,7 +1391,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         lds_fence();
     }
 #ifdef WV_PROF
-    if (wa.dbg && lane < 16) ((unsigned long long*)(wa.dbg + 8192))[gw * 16 + lane] = ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane];
+    if (wa.dbg && lane < 24) ((unsigned long long*)(wa.dbg + 8192))[gw * 24 + lane] = ((WV_LA unsigned long long*)(wb + OFF_PROF))[lane];
 #endif
     WDBG(0xFFFF);
 }
