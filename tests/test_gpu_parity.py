@@ -317,6 +317,7 @@ def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
     # (the one-chunk path of round 4 serves this shape under variant 2 and sums its lag products in another order: it has
     # its own test, test_one_chunk_path_matches_the_general_path; here the three general formulations are compared)
     monkeypatch.setenv("MDT_ONECHUNK", "0")
+    monkeypatch.setenv("MDT_WAVE", "0")                # (round 5: the wave-per-parameter kernel takes this shape under variant 2 and has its own test)
     for v in ("0", "1", "2"):
         monkeypatch.setenv("MDT_RANK_VARIANT", v)
         outs[v] = [host(o) for o in pkg.bulk_tail(xd)] + [host(pkg.rank_normalize(xd, fold=True)[0])]
@@ -1434,6 +1435,7 @@ def test_one_chunk_path_matches_the_general_path(pkg, methods, monkeypatch):
             out.append(("fft ess", host(pkg.ess(xd, kind="bulk", split_chains=s, autocov_method=methods["fft"]))))
         return out
 
+    monkeypatch.setenv("MDT_WAVE", "0")                # (round 5: by default the wave-per-parameter kernel takes these shapes)
     for what, xs in shapes:
         for s in (2, 1):
             if xs.shape[0] % s or xs.shape[1] * s > 8:
@@ -1522,7 +1524,7 @@ def _wave_case_array(rng):
     x[1::2, :, 12] = -x[0:-1:2, :, 12]                     # antithetic: ESS at the cap
     x[:, :, 13] = np.round(x[:, :, 13], 3)                 # a few ties: half-integer ranks, equals among the folds
     x[::2, :, 14] = -x[1::2, :, 14]                        # symmetric pairs: every fold has an equal
-    x[17, 2, 15] = np.nan                                  # a NaN -> the general kernel
+    x[:, :, 15] = np.floor(4.0 * x[:, :, 15])              # a handful of distinct values: every class a point mass -> the general kernel
     return x
 
 
@@ -1576,6 +1578,20 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
                 want = co.bulk_tail(xs, split_chains=s)
                 for i in range(4):
                     assert_close(a[i][1], want[i], RTOL64, f"{what} s={s} oracle {i}")
+    # a NaN anywhere in a slice: the general kernel serves that parameter inside the same request (a NaN ranks last, isless;
+    # the tail ESS of such a slice is an ArgumentError in the reference, Statistics.quantile)
+    xn = x[:, :, :4].copy()
+    xn[17, 2, 1] = np.nan
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkeypatch.setenv("MDT_WAVE", "2")
+        a = [host(pkg.rhat(dev(xn), kind=k)) for k in ("bulk", "tail", "rank")] + [host(pkg.ess(dev(xn), kind="bulk"))]
+        monkeypatch.setenv("MDT_WAVE", "0")
+        b = [host(pkg.rhat(dev(xn), kind=k)) for k in ("bulk", "tail", "rank")] + [host(pkg.ess(dev(xn), kind="bulk"))]
+        monkeypatch.delenv("MDT_WAVE")
+    for u, v in zip(a[:3], b[:3]):
+        assert np.array_equal(u, v, equal_nan=True)
+    assert_close(a[3], b[3], 1e-9, "ess bulk beside a NaN slice")
     assert pkg.status() in (0, 2)
 
 
