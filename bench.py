@@ -31,6 +31,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# The library reads its test / A-B switches only behind MDT_TEST_HOOKS=1.  The bench uses two of them for the diagnostic figures
+# beside the headline (ms_no_order, the workgroup-per-parameter path beside the wave-per-parameter one); every OTHER MDT_* switch
+# is removed from the environment here, so that every reported number is the default path's whatever the caller's shell holds.
+for _k in [k for k in os.environ if k.startswith("MDT_") and k not in ("MDT_LIB", "MDT_BENCH_DRYRUN", "MDT_TEST_HOOKS")]:
+    del os.environ[_k]
+os.environ["MDT_TEST_HOOKS"] = "1"
 
 
 # ---------------------------------------------------------------- synthetic inputs
@@ -263,6 +269,7 @@ def other_configs(pkg, device, steps, warmup):
     # 4 chains), and the shard BASELINE config 4 really puts on one GPU (1 000 000 params over 8 GPUs = 125 000 each, 40 GB)
     for key, (D, C, P), label, nstep in (
             ("config1_at_scale", (1_000, 4, 100_000), "config 1's slice shape (BASELINE.json configs[0]: 1000 draws x 4 chains) at 100000 params", steps),
+            ("short_500x4", (500, 4, 100_000), "500 draws x 4 chains at 100000 params (a short run of a sampler)", steps),
             ("config4_shard", (10_000, 4, 125_000), "one GPU's shard of BASELINE.json configs[3] (1000000 params over 8 GPUs), 40 GB resident", 3)):
         x_pcd = synth(D, C, P, device, seed=1234, chunk=1000 if D >= 10_000 else 10_000)
         x = x_pcd.permute(2, 1, 0)
@@ -273,9 +280,19 @@ def other_configs(pkg, device, steps, warmup):
         xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
         want = c_oracle.bulk_tail(xs)
         b_alg = D * C * 8 + 4 * 8
+        wave = D * C <= 4096
+        extra = {}
+        if wave:  # the same request on the workgroup-per-parameter kernels (what served it until round 4), beside it
+            os.environ["MDT_WAVE"] = "0"
+            try:
+                extra["ms_workgroup_per_parameter_path"] = timed_ms(lambda: pkg.bulk_tail(x, sync=False, out=outs), nstep, 1)
+            finally:
+                del os.environ["MDT_WAVE"]
         out[key] = {
             "workload": f"ess_rhat bulk+tail, {D} draws x {C} chains x {P} params Float64: " + label,
             "ms": ms, "param_series_per_s": P / (ms * 1e-3),
+            "kernel": "mdtw::wave_kernel<double> (one parameter per wave, csrc/mdt_wave.hip)" if wave else "mdt_small::mdt_kernel<double>",
+            **extra,
             "roofline": {"bound": "hbm", "achieved": P * b_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_param": b_alg},
             "parity_max_rel_err_vs_oracle": max_rel_err([o.cpu().numpy()[pick] for o in outs], want),
@@ -286,19 +303,39 @@ def other_configs(pkg, device, steps, warmup):
     return out
 
 
+def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
+    """the fused bulk+tail request over draws x chains shapes at ~1.6 GB of Float64 each: every boundary between the paths
+    (wave-per-parameter kernel up to 4096 values per slice, 256- / 512-thread workgroups per parameter beyond) is visible
+    in the driver's record"""
+    rows = []
+    for D in (250, 500, 1_000, 2_000, 5_000, 10_000):
+        for C in (2, 4, 8):
+            P = max(256, int(target_bytes / (8 * D * C)))
+            x_pcd = synth(D, C, P, device, seed=99, chunk=max(500, min(20_000, int(2e8 / (8 * D * C)))))
+            x = x_pcd.permute(2, 1, 0)
+            outs = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
+            ms = timed_ms(lambda: pkg.bulk_tail(x, sync=False, out=outs), steps, 1)
+            b_alg = D * C * 8 + 4 * 8
+            rows.append({"draws": D, "chains": C, "params": P, "ms": round(ms, 3), "param_series_per_s": round(P / (ms * 1e-3), 1),
+                         "hbm_frac": round(P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "path": "wave" if D * C <= 4096 and D // 2 <= 640 else ("wg256" if D * C <= 12288 and D // 2 <= 1392 else "wg512")})
+            del x, x_pcd, outs
+            torch.cuda.empty_cache()
+    return {"note": "bulk+tail, split_chains 2, maxlag 250, ~1.6 GB of Float64 per shape, 3 timed steps after 1 warm-up; path = which kernel "
+                    "family serves the shape by default", "rows": rows, "status_flags": pkg.status()}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py <same
     arguments>` as a CHILD process (never an exec: this process has not touched the GPU, and must not replace itself once
     it has) and return its exit code.  Rank 0 of the child prints the JSON line."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks its own rendezvous port (binding a socket here to find a free one, closing it and passing
+    # the number on left a window in which another process could take it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -333,6 +370,8 @@ def main():
     ap.add_argument("--draws", type=int, default=10_000)
     ap.add_argument("--chains", type=int, default=4)
     ap.add_argument("--params", type=int, default=10_000, help="parameters per GPU")
+    ap.add_argument("--config4", action="store_true",
+                    help="BASELINE.json configs[3]: 125000 parameters per GPU (1000000 over 8 GPUs, 40 GB resident per GPU); same as --params 125000")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget for the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true",
@@ -344,6 +383,8 @@ def main():
     ap.add_argument("--autocov", choices=("direct", "fft", "bda"), default="direct",
                     help="autocov_method of the request (BASELINE config 3 forces fft)")
     args = ap.parse_args()
+    if args.config4:
+        args.params = 125_000
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -388,8 +429,9 @@ def main():
         pkg = g.load_package()
         x_pcd = synth(D, C, P, device, seed=1234, p0=rank * P)   # rank r owns global parameters [r P, (r + 1) P): generated on its GPU
     x = x_pcd.permute(2, 1, 0)                          # logical (draws, chains, params), zero-copy
-    outs = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
-    gathered = [torch.empty(world * P, dtype=torch.float64, device=device) for _ in range(4)] if world > 1 else None
+    outs4 = torch.empty((4, P), dtype=torch.float64, device=device)   # the four output vectors, packed: ONE all-gather per step
+    outs = [outs4[k] for k in range(4)]
+    gathered = torch.empty((world, 4, P), dtype=torch.float64, device=device) if world > 1 else None
 
     method = {"direct": pkg.AutocovMethod, "fft": pkg.FFTAutocovMethod, "bda": pkg.BDAAutocovMethod}[args.autocov]()
 
@@ -406,8 +448,7 @@ def main():
             return
         pkg.bulk_tail(x, autocov_method=method, sync=False, out=outs)
         if world > 1:
-            for o, gbuf in zip(outs, gathered):
-                dist.all_gather_into_tensor(gbuf, o)
+            dist.all_gather_into_tensor(gathered.view(-1), outs4.view(-1))   # (flat views: one contiguous [4 P] block per rank)
 
     # A diagnostic is normally called ONCE per array.  The first request of a process pays for the context (scratch
     # allocation, the score table of the shape) and runs its tickets in parameter order; the next ones run them in the
@@ -416,12 +457,31 @@ def main():
     # -- after the timed loop -- the steady state with the order switched off (ms_no_order).
     cold = {}
     if not dry and not streams and world == 1:
-        for name in ("first_call_ms", "second_call_ms"):
+        def wall_ms(fn):
             dev_sync()
             tc = time.perf_counter()
-            step()
+            fn()
             dev_sync()
-            cold[name] = (time.perf_counter() - tc) * 1e3
+            return (time.perf_counter() - tc) * 1e3
+        # (a) what a user's ONE call costs on a fresh context: context (code object, status words), scratch and ticket tables,
+        # the score table of the shape, the launch -- measured on a side stream, whose context nothing else here uses
+        side = torch.cuda.Stream(device=device)
+        outs_side = [torch.empty(P, dtype=torch.float64, device=device) for _ in range(4)]
+
+        def first_on_side():
+            with torch.cuda.stream(side):
+                pkg.bulk_tail(x, autocov_method=method, sync=False, out=outs_side)
+        cold["first_call_ms"] = wall_ms(first_on_side)
+        # (b) the same with the shape announced first (mdt_ctx_reserve): creating the context, reserving, then the first request
+        cur = torch.cuda.current_stream(device).cuda_stream
+        cold["ctx_create_ms"] = wall_ms(lambda: pkg._lib.ctx(device.index, cur))
+        cold["ctx_reserve_ms"] = wall_ms(lambda: pkg.reserve(D, C, P, dtype=np.float64))
+        cold["first_request_ms"] = wall_ms(step)
+        cold["second_call_ms"] = wall_ms(step)
+        cold["first_call_note"] = ("first_call_ms: one call on a fresh context (context + allocations + score table + launch in parameter order); "
+                                   "ctx_create_ms / ctx_reserve_ms / first_request_ms: the same split up -- with mdt_ctx_reserve(shape) called "
+                                   "beforehand the first request pays the launch only (tickets in parameter order: no cost history yet)")
+        del outs_side
     for _ in range(args.warmup):
         step()
     dev_sync()
@@ -444,14 +504,14 @@ def main():
     dev_sync()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps if not dry else elapsed / args.steps * 1e3  # HIP events on the stream the kernel runs on
-    if world > 1:  # the gather did what it is there for: every rank holds every rank's block
-        for gbuf in gathered:
-            for r in range(world):
-                blk = gbuf[r * P:(r + 1) * P]
+    if world > 1:  # the gather did what it is there for: every rank holds every rank's block of every output
+        for r in range(world):
+            for k in range(4):
+                blk = gathered[r, k]
                 if dry:
                     assert torch.equal(blk, torch.arange(r * P, (r + 1) * P, dtype=blk.dtype)), "gathered block mismatch"
         if not dry:
-            assert all(torch.equal(gbuf[rank * P:(rank + 1) * P], o) for gbuf, o in zip(gathered, outs)), "gathered block mismatch"
+            assert torch.equal(gathered[rank], outs4), "gathered block mismatch"
     # the timed requests were asynchronous: what they could not raise is on the context (mdt_ctx_status)
     status_flags = pkg.status() if not streams else 0
     if status_flags:
@@ -607,6 +667,7 @@ def main():
         del x, x_pcd
         torch.cuda.empty_cache()
         res["other_configs"] = other_configs(pkg, device, steps=5, warmup=1)
+        res["other_configs"]["shape_sweep"] = shape_sweep(pkg, device)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

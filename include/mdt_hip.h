@@ -38,7 +38,8 @@
 extern "C" {
 #endif
 
-#define MDT_VERSION 300 /* 0.3.0: mdt_args gained x_shards (pre-sharded input of a multi-GPU context); mdt_shard_bounds; mdt_mcse_nested */
+#define MDT_VERSION 310 /* 0.3.1: mdt_ctx_reserve (the allocations of a shape before its first request); 0.3.0: mdt_args gained x_shards
+                           (pre-sharded input of a multi-GPU context); mdt_shard_bounds; mdt_mcse_nested */
 
 /* status codes (the Julia shim maps them to the reference's exception types) */
 #define MDT_OK 0
@@ -108,6 +109,15 @@ int mdt_version(void);
 int mdt_ctx_create(mdt_ctx** out, int device_id);
 int mdt_ctx_destroy(mdt_ctx* ctx);
 const char* mdt_last_error(const mdt_ctx* ctx);
+/*
+ * Optional: everything a request of this shape would otherwise allocate and build inside its FIRST call -- the per-workgroup
+ * and per-wave scratch, the normal-score table of (draws * chains, dtype) (src/utils.jl:182, 189-193: built once per shape),
+ * the ticket tables of `params` parameters -- so that the first mdt_ess_rhat / mdt_bulk_tail / ... on the context costs what
+ * every later one costs.  A diagnostic is typically called once per array: call this when the sampler's shape is known
+ * (args: draws, chains, params, dtype, stream; the rest is ignored).  The reference has no counterpart: its caches are the
+ * per-call temporaries of src/ess_rhat.jl:511 and src/utils.jl:170-171.  Returns MDT_OK, MDT_EARG, MDT_ENOMEM, MDT_ERUNTIME.
+ */
+int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* args);
 
 /*
  * One context over several GPUs of the node: every parameter is independent (the `for` over

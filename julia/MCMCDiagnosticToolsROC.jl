@@ -120,6 +120,20 @@ function status(; devices=nothing, clear::Bool=true)
     return f[]
 end
 
+"""    reserve(draws, chains, params; T=Float64, devices=nothing)
+
+Allocate and build, before the first request, what a `(draws, chains, params)` array of eltype `T` needs on the context
+(mdt_ctx_reserve): scratch, the normal-score table of the shape, ticket tables.  Optional -- a diagnostic is usually
+called once per array, and without this its one call also pays for the allocations."""
+function reserve(draws::Integer, chains::Integer, params::Integer; T::Type{<:Union{Float64,Float32}}=Float64, devices=nothing)
+    h = _ctx_for(devices)
+    a = MdtArgs(draws, chains, params, T === Float32 ? 1 : 0, 1, 0, 0, 0, 2, 0, 1, 250, 0.1, C_NULL)
+    _locked() do
+        _check(h, ccall((:mdt_ctx_reserve, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}), h, a))
+    end
+    return nothing
+end
+
 """    shard_bounds(P, i, n) -> (lo, hi)
 
 Block `i` (0-based) of `n` of a params axis of length `P`, as the half-open 0-based range the library cuts by

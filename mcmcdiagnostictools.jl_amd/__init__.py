@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     mcse,
     mcse_rhat_nested,
     rank_normalize,
+    reserve,
     rhat,
     rhat_nested,
     status,

@@ -19,7 +19,7 @@ KIND = {"basic": 0, "bulk": 1, "tail": 2, "rank": 3, "median": 4, "std": 5, "mad
 OUT_ESS, OUT_RHAT = 1, 2
 
 # every symbol include/mdt_hip.h declares
-SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_create_multi", "mdt_shard_bounds", "mdt_ctx_destroy", "mdt_ctx_status", "mdt_last_error", "mdt_ess_rhat",
+SYMBOLS = ("mdt_version", "mdt_ctx_create", "mdt_ctx_reserve", "mdt_ctx_create_multi", "mdt_shard_bounds", "mdt_ctx_destroy", "mdt_ctx_status", "mdt_last_error", "mdt_ess_rhat",
            "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile", "mdt_rank_normalize", "mdt_layout_from_dpc",
            "mdt_bfmi", "mdt_gelmandiag", "mdt_debug_phase_cycles", "mdt_debug_beta")
 
@@ -82,6 +82,7 @@ def load():
         lib.mdt_ctx_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int]
         lib.mdt_ctx_create_multi.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int), ctypes.c_int]
         lib.mdt_ctx_status.argtypes = [vp, ctypes.POINTER(i32), i32]
+        lib.mdt_ctx_reserve.argtypes = [vp, ap]
         lib.mdt_shard_bounds.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
         lib.mdt_ctx_destroy.argtypes = [vp]
         lib.mdt_last_error.argtypes = [vp]

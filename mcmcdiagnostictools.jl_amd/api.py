@@ -265,6 +265,26 @@ def status(device=None, *, devices=None, clear=True):
 FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = _lib.FLAG_RANK_OVERFLOW, _lib.FLAG_NAN_QUANTILE, _lib.FLAG_FDIST
 
 
+def reserve(draws, chains, params, *, dtype=np.float64, device=None, devices=None):
+    """Allocate and build, before the first request, what a (draws, chains, params) array of `dtype` needs on the context
+    of (device, current stream) -- or of the multi-GPU context over `devices` -- : scratch, the normal-score table of
+    the shape, ticket tables (mdt_ctx_reserve).  Optional: a diagnostic is usually called once per array, and without
+    this its one call also pays for the allocations.  No counterpart in the reference (its caches are per-call
+    temporaries, src/ess_rhat.jl:511)."""
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
+        raise ArgumentError("dtype must be float64 or float32")
+    if devices is not None:
+        key, stream = (tuple(int(d) for d in devices), None), None
+    else:
+        dev = torch.cuda.current_device() if device is None else int(device)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        key = (dev, stream)
+    a = _lib.MdtArgs(int(draws), int(chains), int(params), _lib.MDT_F32 if dt == np.dtype(np.float32) else _lib.MDT_F64,
+                     _lib.MDT_DEVICE, 0, 0, 0, 2, 0, 1, 250, 0.1, stream, 0, 0)
+    _call(key, _lib.load().mdt_ctx_reserve, ctypes.byref(a))
+
+
 def _finish(pr, out):
     """param axes, Missing and scalar conventions of the reference (src/utils.jl:197-215)"""
     if out is None:

@@ -1119,6 +1119,68 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
     return MDT_OK;
 }
 
+int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
+    if (!ctx) return MDT_EARG;
+    if (!a) return fail(ctx, MDT_EARG, "args is NULL");
+    if (!ctx->children.empty()) { // every block on its own GPU, sized for its share of the params axis
+        for (size_t i = 0; i < ctx->children.size(); ++i) {
+            long long lo, hi;
+            shard_bounds(a->params, (int)i, (int)ctx->children.size(), &lo, &hi);
+            mdt_args b = *a;
+            b.params = hi - lo;
+            b.stream = nullptr;
+            const int rc = mdt_ctx_reserve(ctx->children[i], &b);
+            if (rc) return fail(ctx, rc, ctx->children[i]->err);
+        }
+        return MDT_OK;
+    }
+    if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
+    if (a->draws <= 0 || a->chains <= 0 || a->params < 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
+    const long long n = a->draws * a->chains, P = a->params;
+    if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
+    MDT_ON_DEVICE(ctx);
+    hipStream_t st = (hipStream_t)a->stream;
+    if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    // the largest grid a request of this slice size can take (four 256-thread workgroups per CU serve slices of <= 12288 values)
+    const long long wgs = n <= 12288 ? 2LL * ctx->grid : ctx->grid;
+    if (int rc = ensure_scratch(ctx, n, wgs)) return rc;
+    if (int rc = ensure_ztab(ctx, n, a->dtype == MDT_F32 ? 1 : 0, st)) return rc;
+    if (n >= 256 && n <= (long long)mdtw::WV_MAXN) {
+        const mdtw::Geo g = mdtw::geometry(n, a->dtype == MDT_F32 ? 1 : 0);
+        const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
+        const size_t need = mdtw::scratch_bytes(g, (long long)ncu * g.waves);
+        if (need > ctx->wv_cap) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->wv_scratch) (void)hipFree(ctx->wv_scratch);
+            ctx->wv_scratch = nullptr; ctx->wv_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->wv_scratch, need));
+            ctx->wv_cap = need;
+        }
+    }
+    if (P > ctx->fb_cap && n <= (long long)mdtw::WV_MAXN) {
+        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        if (ctx->fb_list) (void)hipFree(ctx->fb_list);
+        ctx->fb_list = nullptr; ctx->fb_cap = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->fb_list, (size_t)std::max<long long>(P, 1) * sizeof(unsigned int)));
+        ctx->fb_cap = P;
+    }
+    if (P > ctx->order_cap && P < 0xFFFFFFFFLL) {
+        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        if (ctx->cost) (void)hipFree(ctx->cost);
+        if (ctx->order) (void)hipFree(ctx->order);
+        if (ctx->order_sorted) (void)hipFree(ctx->order_sorted);
+        ctx->cost = nullptr; ctx->order = nullptr; ctx->order_sorted = nullptr; ctx->order_cap = 0; ctx->order_P = -1;
+        HIP_TRY(hipMalloc((void**)&ctx->cost, (size_t)P * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc((void**)&ctx->order, (size_t)P * sizeof(unsigned int)));
+        HIP_TRY(hipMalloc((void**)&ctx->order_sorted, (size_t)P * sizeof(unsigned int)));
+        ctx->order_cap = P;
+    }
+    ctx->last_stream = st;
+    ctx->used = true;
+    HIP_TRY(hipStreamSynchronize(st)); // the score table is built when this returns
+    return MDT_OK;
+}
+
 int mdt_ctx_destroy(mdt_ctx* ctx) {
     if (!ctx) return MDT_OK;
     if (!ctx->children.empty()) {

@@ -39,15 +39,40 @@ def gather_params(local, nparams, group=None):
     return torch.cat(parts)
 
 
+def gather_params_packed(locals_, nparams, group=None):
+    """the same for SEVERAL per-parameter outputs at once: ONE all-gather of a packed [K, cap] block per rank instead of K
+    latency-bound collectives (K = 4 for bulk+tail); returns the K full [nparams] vectors"""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    q, r = divmod(int(nparams), world)
+    cap = q + (1 if r else 0)
+    K = len(locals_)
+    first = torch.as_tensor(locals_[0])
+    pad = torch.zeros((K, cap), dtype=first.dtype, device=first.device)
+    lo, hi = shard_bounds(nparams, rank, world)
+    for k, o in enumerate(locals_):
+        pad[k, : hi - lo] = torch.as_tensor(o).reshape(-1)
+    buf = torch.empty((world, K, cap), dtype=first.dtype, device=first.device)
+    dist.all_gather_into_tensor(buf.view(-1), pad.view(-1), group=group)
+    outs = []
+    for k in range(K):
+        parts = []
+        for rk in range(world):
+            l2, h2 = shard_bounds(nparams, rk, world)
+            parts.append(buf[rk, k, : h2 - l2])
+        outs.append(torch.cat(parts))
+    return tuple(outs)
+
+
 def ess_rhat_sharded(local_samples, nparams_total, *, compute=None, group=None, **kwargs):
     """bulk+tail diagnostics of a params-sharded array.
 
     local_samples: this rank's block, shape (draws, chains, hi - lo) with (lo, hi) =
     shard_bounds(nparams_total, rank, world).  Returns the four full-length vectors
-    (ess_bulk, ess_tail, rhat_bulk, rhat_tail) on every rank.
+    (ess_bulk, ess_tail, rhat_bulk, rhat_tail) on every rank: one packed all-gather.
     `compute` defaults to the HIP path (api.bulk_tail); tests inject a checker.
     """
     if compute is None:
         from .api import bulk_tail as compute
     outs = compute(local_samples, **kwargs)
-    return tuple(gather_params(torch.as_tensor(o), nparams_total, group) for o in outs)
+    return gather_params_packed([torch.as_tensor(o) for o in outs], nparams_total, group)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in declared_functions():
         assert hasattr(lib, name), name
     lib.mdt_version.restype = ctypes.c_int
-    assert lib.mdt_version() == 300
+    assert lib.mdt_version() == 310
 
 
 def test_struct_layout_matches_header():
