@@ -192,6 +192,43 @@ def max_rel_err(got, want):
     return err
 
 
+N_SIMD, MAX_CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs; /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def committed_counters():
+    """profiles/traffic.json: calibrated memory-side bytes and SQ instruction counters per launch of the measured workloads, from
+    the committed rocprofv3 --pmc passes of the same workloads (tools/collect_profiles.sh + tools/summarize_profiles.py); not
+    measured in this run"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)
+    except Exception:
+        return {}
+
+
+def counter_bounds(tj, key, shape, ms):
+    """(traffic, issue) of workload `key` when the committed counters are of this shape.  issue: the second roofline of the
+    line -- these launches are bound by vector instruction issue, not by HBM: a SIMD issues one wave64 vector instruction per
+    4 cycles at best (one wave's stream; the f64 operations that dominate here run below that), and while a v_mfma_f64 executes
+    (SQ_VALU_MFMA_BUSY_CYCLES) nothing else issues on its SIMD (measured): floor = (4 (VALU - MFMA instructions) +
+    MFMA busy cycles) / 1024 SIMDs / 2.4 GHz; frac = floor / measured duration."""
+    w = (tj.get("workloads") or {}).get(key)
+    if not w or (w.get("draws"), w.get("chains"), w.get("params")) != tuple(shape):
+        return None, None
+    src = f"profiles/traffic.json ({tj.get('profile')}: separate rocprofv3 --pmc passes of this workload; FETCH_SIZE / WRITE_SIZE calibrated on a copy kernel of known size in the same session; not measured in this run)"
+    traffic = {"bytes_per_launch": w.get("memory_side_bytes_per_launch"), "over_algorithmic": w.get("traffic_over_algorithmic"), "source": src}
+    issue = None
+    if w.get("valu_wave_insts"):
+        mf, mb = w.get("mfma_wave_insts") or 0.0, w.get("mfma_busy_cycles") or 0.0
+        floor_ms = (4.0 * (w["valu_wave_insts"] - mf) + mb) / N_SIMD / MAX_CLOCK_HZ * 1e3
+        issue = {"bound": "vector instruction issue", "valu_wave_insts": w["valu_wave_insts"], "mfma_wave_insts": mf, "mfma_busy_cycles": mb,
+                 "floor_ms": floor_ms, "frac": floor_ms / ms if ms else None,
+                 "model": "(4 cycles x (VALU - MFMA wave-instructions) + MFMA busy cycles) / 1024 SIMDs / 2.4 GHz", "source": src}
+        if w.get("valu_active_quad_cycles") and w.get("wave_quad_cycles"):
+            issue["valu_active_over_wave_cycles"] = w["valu_active_quad_cycles"] / w["wave_quad_cycles"]
+    return traffic, issue
+
+
 def other_configs(pkg, device, steps, warmup):
     """BASELINE configs 3 and 5 (per-GPU shard) measured in the same run: time per call, param-series/s, the
     HBM-roofline fraction on algorithmic bytes, and the oracle on a few parameters of the timed array."""
@@ -300,6 +337,16 @@ def other_configs(pkg, device, steps, warmup):
         }
         del x, x_pcd, outs
         torch.cuda.empty_cache()
+    tj = committed_counters()
+    for key, ckey, shape in (("config3", "cfg3", (100_000, 8, 1_000)), ("config5_shard", "cfg5", (10_000, 16, 12_500)),
+                             ("config1_at_scale", "cfg1", (1_000, 4, 100_000)), ("short_500x4", "s500", (500, 4, 100_000))):
+        traffic, issue = counter_bounds(tj, ckey, shape, out[key]["ms"])
+        out[key]["roofline"]["traffic"] = traffic["bytes_per_launch"] if traffic else None
+        if traffic:
+            out[key]["roofline"]["traffic_over_algorithmic"] = traffic["over_algorithmic"]
+            out[key]["roofline"]["traffic_source"] = traffic["source"]
+        if issue:
+            out[key]["roofline"]["issue"] = issue
     return out
 
 
@@ -571,18 +618,18 @@ def main():
                                  "about 60 % busy at four waves per SIMD (profiles/r04f_pmc_phases_cfg2.txt, DESIGN.md 5d)"),
             },
         }
-        # traffic per launch from the committed PMC profile of this same command, if present
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("draws") == D and tj.get("chains") == C and tj.get("params") == P:
-                    res["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                    res["roofline"]["traffic_source"] = ("profiles/traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                                         "workload, calibrated on a copy kernel of known size (not measured in this run)")
-            except Exception:
-                pass
+        # traffic per launch and the instruction-issue bound from the committed PMC profile of this same workload, if present
+        tj = committed_counters()
+        traffic, issue = counter_bounds(tj, "cfg2", (D, C, P), kernel_ms)
+        if traffic:
+            res["roofline"]["traffic"] = traffic["bytes_per_launch"]
+            res["roofline"]["traffic_source"] = traffic["source"]
+        if issue:
+            res["roofline"]["issue"] = issue
+            res["roofline"]["limiter_note"] = (
+                "the nominal bound of this scan/sort/reduce path is HBM (SURVEY.md 8d); what limits the launch is vector instruction issue "
+                f"(roofline.issue: {issue['valu_wave_insts']:.3g} vector wave-instructions per launch, floor {issue['floor_ms']:.2f} ms) and dependent "
+                f"LDS / L2 round trips between barriers; counters: profiles/{tj.get('profile')}_counters.txt, phases: DESIGN.md")
 
         if dry:
             res["dry_run"] = True

@@ -231,11 +231,7 @@ struct SrcPlain {      // x itself
     __device__ __forceinline__ void make_uniform() { xp = (const MDT_GA T*)uni64((unsigned long long)xp); }
     __device__ __forceinline__ double operator()(long long e) const { return (double)xp[e]; }
     // element base + i with a wave-uniform base: scalar base register + 32-bit lane offset, no 64-bit address math
-#ifdef MDT_NT_X /* experiment: stream x past the caches */
-    __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)__builtin_nontemporal_load((xp + base) + i); }
-#else
     __device__ __forceinline__ double at(long long base, unsigned i) const { return (double)(xp + base)[i]; }
-#endif
     // the one read of a pass that takes the slice once (tile-major pass)
     __device__ __forceinline__ double at_stream(long long base, unsigned i) const { return (double)MDT_LD_STREAM((xp + base) + i); }
 };
@@ -296,16 +292,12 @@ struct SerZ {          // series = normal scores, already in time order in the p
     __device__ __forceinline__ double operator()(int c, long long row) const { return z[(long long)c * D + row]; }
 };
 #define MDT_PHASE __device__ __attribute__((noinline))
-// The phases of the common path (two-level ranking, z-series, fold merge, pooled indicators).  As separate functions each
-// call saves and restores the 48 callee-saved VGPRs it touches: ~100 KB of scratch stores and as many loads per workgroup and
-// call.  MDT_INLINE_HOT builds them into the kernel body instead (A/B timing).  Measured in round 3: all four +27 %; through
-// impl / wrapper pairs, only the call site of the common path: the ranking +5 %, the z-series +2 %, fold merge + indicators
-// +18 % -- the register allocation of the one large function loses more than the frames cost.
-#ifdef MDT_INLINE_HOT
-#define MDT_PHASE_HOT __device__ __forceinline__
-#else
+// The phases of the common path (two-level ranking, z-series, fold merge, pooled indicators) are separate functions: each
+// call saves and restores the 48 callee-saved VGPRs it touches (~100 KB of scratch stores and as many loads per workgroup and
+// call), and still wins -- built into the kernel body they were measured in round 3 at +27 % (all four), +5 % / +2 % / +18 %
+// (ranking / z-series / fold merge + indicators alone): the register allocation of one large function loses more than the
+// frames cost.
 #define MDT_PHASE_HOT MDT_PHASE
-#endif
 // The dynamic LDS block reaches the phase functions as a plain pointer, but the compiler knows which symbol it is and
 // re-derives its address wherever it is used -- in a function that is not a kernel that is a LOAD from a table in
 // global memory (llvm.amdgcn.dynlds.offset.table), rematerialised inside hot loops (17 exposed L2 round trips in
@@ -581,7 +573,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const SerZ YZ{(const MDT_GA double*)zb, D};
         // (a chain is processed in blocks of 64 values -- the last one zero-padded -- and the shifted operand of a lag tile
         // reaches maxlag + 16 past it: 63 + 16 + 1 values of room behind niter + maxlag)
-        const bool zfast = (kp.niter + kp.maxlag + 80 <= SZ) && (kp.maxlag < SZ_EDGE);
+        const bool zfast = (kp.niter + kp.maxlag + Z_MARGIN <= SZ) && (kp.maxlag < SZ_EDGE);
 
         if (kp.niter == 0) { // mean of nothing: everything is NaN (src/ess_rhat.jl:391-406 with niter = 0)
             if (tid == 0) {
@@ -763,10 +755,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
         const bool need_rank_x = kp.need_eb || kp.need_rb || need_med || need_q || (kp.mode == 3 && !kp.fold) || kp.mode == 5;
         // the z-series phase can take the scores in segment order (no scattered store in the ranking at all)
         const bool seg_req = zfast && !fft_lds && kp.mode != 3;
-        // chains that cannot fit the LDS whatever maxlag is (so that rhat(x), which runs with maxlag = 1, and
+        // chains that cannot fit the LDS whatever maxlag is -- the zfast test above with the smallest maxlag, 1: ONE margin for both
+        // predicates, so that no chain length falls between them (until round 4 the margins were 80 and 40: split chains of SZ - 80
+        // ... SZ - 41 draws were neither, and took the slow double pass) -- (so that rhat(x), which runs with maxlag = 1, and
         // ess_rhat(x) decide alike and their R-hat stays the same bits): the ranking delivers the moments itself and,
         // when an autocovariance follows, the windowed score layout of series_win_phase instead of a time-order scatter
-        const bool long_chain = kp.winout && kp.niter + 41 > SZ && !fft_lds && kp.mode != 3 && kp.m + 1 <= 64 &&
+        const bool long_chain = kp.winout && kp.niter + 1 + Z_MARGIN > SZ && !fft_lds && kp.mode != 3 && kp.m + 1 <= 64 &&
                                 kp.maxlag + 40 + MAXROUNDS <= PT_CAP / 4;
         int rk = 0; // what the last ranking left in zb: 2 = segment order, otherwise time order; 5: the scores are in LDS (one-chunk path)
         // short slices: the whole parameter in one LDS chunk (mdt_short.inc); a NaN in the slice sends it down the general path

@@ -205,8 +205,10 @@ int mdt_oracle_bulk_tail_omp_f64(const mdt_oracle_args* a, const double* x, doub
     mallopt(M_MMAP_THRESHOLD, 32 << 20); /* (glibc's ceiling: HEAP_MAX_SIZE / 2; a block's largest temporary is a few MB) */
     mallopt(M_TRIM_THRESHOLD, 1 << 30);
     mallopt(M_TOP_PAD, 64 << 20);
-    /* process-wide settings: put back to glibc's defaults after the parallel region (below), so that whatever the host
-     * process measures afterwards runs with the allocator it would have had without this call */
+    /* process-wide settings: put back to glibc's DEFAULT VALUES after the parallel region (below).  Not the allocator the process
+     * would have had without this call: setting any of the three switches glibc's DYNAMIC mmap threshold off for good, so
+     * whatever the host process measures on the CPU afterwards runs with a fixed 128 KiB threshold.  bench.py runs this
+     * leg after the single-thread baseline of the line (cpu_baseline), which is the contractual one. */
 #ifdef _OPENMP
     if (nthreads < 1) nthreads = omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)

@@ -1633,3 +1633,26 @@ print(json.dumps([o.cpu().numpy().tolist() for o in pkg.bulk_tail(xd)]))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1]
+
+
+def test_chain_lengths_between_the_lds_resident_and_the_windowed_series(pkg, methods):
+    """Split chains of SZ - 80 ... SZ - 41 draws (SZ = 6400 doubles of chain buffer in the 512-thread geometry) were neither
+    `zfast` (chain resident in LDS) nor `long_chain` (windowed series) until round 4 -- two margins, 80 and 40 -- and took the
+    slow double pass; both predicates now derive from one constant.  6340 draws per split chain: against the oracle, and
+    rhat(x) == ess_rhat(x).rhat bit for bit as everywhere."""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(77)
+    for niter in (6340, 6321, 6359):
+        x = ar1(0.5, 2 * niter, 2, 5, rng)
+        x[:, :, 1] = rng.standard_normal((2 * niter, 2))
+        xd = dev(x)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = [host(o) for o in pkg.bulk_tail(xd)]
+            want = co.bulk_tail(x)
+            for a, b, nm in zip(got, want, ("ess_bulk", "ess_tail", "rhat_bulk", "rhat_tail")):
+                assert_close(a, b, RTOL64, f"{nm} niter {niter}")
+            assert np.array_equal(host(pkg.rhat(xd, kind="bulk")), got[2])
+            assert np.array_equal(host(pkg.rhat(xd, kind="tail")), got[3])
+            assert_close(host(pkg.ess(xd, kind="bulk", autocov_method=methods["fft"])), co.ess_rhat(x, kind="bulk", autocov="fft")[0], RTOL64, f"fft niter {niter}")

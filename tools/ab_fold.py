@@ -6,6 +6,8 @@
 """
 import argparse
 import os
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -5,6 +5,8 @@ kinds, autocov methods, data flavours and geometries against the C oracle.  pyth
 order: 600 - 4000 short parameters per request, each request issued twice -- the second launch hands its tickets out by
 the costs the first one measured.  Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
 import os, sys, time, warnings
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,4 +1,6 @@
 import sys, time, numpy as np, torch
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 sys.path.insert(0, "/root/repo")
 import __graft_entry__ as g
 pkg = g.load_package()

@@ -10,6 +10,8 @@ stamps themselves perturb nothing but they are summed over all workgroups.
 import argparse
 import ctypes
 import os
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 import sys
 
 os.environ.setdefault("MDT_PROF", "1")

@@ -1,97 +1,139 @@
 #!/usr/bin/env python3
-"""Turn gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/."""
-import csv, glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+"""Turn gpurun_out/<tag>/ (tools/collect_profiles.sh) into the committed summaries under profiles/:
+  <tag>_bench.json, <tag>_bench_under_rocprof.json   the bench line, plain and under rocprofv3
+  <tag>_kernel_stats.csv                              rocprofv3 --stats of the FULL bench command (a row per kernel instantiation)
+  <tag>_kernel_dispatches.txt                         every dispatch of the engine's kernels in that run, by kernel, in launch order
+  <tag>_pmc_<workload>.csv, <tag>_pmc_cal.csv         raw counter rows (FETCH_SIZE / WRITE_SIZE / SQ_*) of the engine's kernels
+  <tag>_counters.txt                                  the same as a table: per workload and launch
+  <tag>_phase_*.txt, <tag>_strided.txt, <tag>_kinds.txt
+  traffic.json                                        what bench.py reads: calibrated memory-side bytes and the instruction-issue
+                                                      counters per launch of every measured workload
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
-shutil.copy(os.path.join(src, "bench.json"), f"profiles/{tag}_bench.json")
+for name in ("bench.json", "bench_under_rocprof.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, f"profiles/{tag}_{name}")
 for f in glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")):
     with open(f) as fi, open(f"profiles/{tag}_kernel_stats.csv", "w") as fo:   # (torch's generator kernels have names of several KB)
         w = csv.writer(fo)
         for row in csv.reader(fi):
             row[0] = row[0][:100]
             w.writerow(row)
-# per-dispatch durations of the engine's kernels in the profiled bench run, in launch order (the first steps + warmup
-# dispatches of mdt_small::mdt_kernel<double> are the headline's; rocprofv3's own avg above includes the cold first call)
+
+ENGINE = ("mdt_kernel", "wave_kernel")
 tr = glob.glob(os.path.join(src, "stats", "*", "*kernel_trace.csv"))
 if tr:
     disp = {}
     for r in csv.DictReader(open(tr[0])):
-        if "mdt_kernel" in r["Kernel_Name"]:
-            disp.setdefault(r["Kernel_Name"][:60], []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        if any(k in r["Kernel_Name"] for k in ENGINE):
+            key = (r["Kernel_Name"][:70], r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?"))
+            disp.setdefault(key, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
     try:
         under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
     except Exception:
         under = None
     with open(f"profiles/{tag}_kernel_dispatches.txt", "w") as fo:
         sw = f"--steps {under['steps']} --warmup {under['warmup']} " if under else ""
-        fo.write(f"# rocprofv3 --kernel-trace of `python3 bench.py {sw}--no-cpu-baseline --no-other-configs`: duration of every dispatch, ms, in launch order\n")
-        fo.write("# (headline kernel: first call, second call, the warm-up steps, the timed steps, then 1 + steps launches with MDT_NO_ORDER=1)\n")
+        fo.write(f"# rocprofv3 --kernel-trace of `python3 bench.py {sw}--no-cpu-baseline` (the FULL line: headline, configs 3 / 5-shard / 1-at-scale /\n"
+                 "# 500x4 / 4-shard, shape sweep): duration of every dispatch of the engine's kernels, ms, by (kernel, grid, workgroup) in launch order\n")
         if under:
             fo.write(f"# the same run's own line: ms_per_step {under['ms_per_step']:.3f}, roofline.kernel_ms (HIP events) {under['roofline']['kernel_ms']:.3f}\n")
-        for k, v in disp.items():
+            oc = under.get("other_configs", {})
+            fo.write("# its other_configs (HIP events): " + ", ".join(f"{k} {v['ms']:.2f} ms" for k, v in oc.items() if isinstance(v, dict) and "ms" in v) + "\n")
+        for k, v in sorted(disp.items(), key=lambda kv: min(x[0] for x in kv[1])):
             d = [x[1] for x in sorted(v)]
-            fo.write(f"{k}: n={len(d)} mean={sum(d) / len(d):.3f} min={min(d):.3f} max={max(d):.3f}\n  " + " ".join(f"{x:.2f}" for x in d) + "\n")
-            if "small" in k and "double" in k and under and len(d) >= under["steps"] + under["warmup"]:
-                w0 = under["warmup"] + (2 if "first_call_ms" in under else 0)
+            fo.write(f"{k[0]} grid {k[1]} wg {k[2]}: n={len(d)} mean={sum(d) / len(d):.3f} min={min(d):.3f} max={max(d):.3f}\n  "
+                     + " ".join(f"{x:.2f}" for x in d[:80]) + (" ..." if len(d) > 80 else "") + "\n")
+            if under and "mdt_small" in k[0] and "double" in k[0] and k[1] == str(512 * 512) and len(d) >= under["steps"] + under["warmup"] + 3:
+                # the headline's launches come first: the side-stream first call is another context (same kernel, same grid),
+                # then first request, second call, warm-up, the timed steps, then 1 + steps launches with MDT_NO_ORDER=1
+                w0 = under["warmup"] + 3
                 t = d[w0:w0 + under["steps"]]
-                fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)}): mean {sum(t) / len(t):.3f} ms\n")
-for name in ("phase_cfg2", "phase_cfg3", "phase_cfg2_rank", "phase_cfg2_fold", "phase_cfg3_rank", "phase_cfg3_fold", "phase_cfg5_rank", "phase_cfg5_fold",
-             "phase_cfg1", "phase_cfg1_fold", "pmc_phases_cfg2", "pmc_phases_cfg3", "pmc_phases_cfg5", "mfma_microbench",
-             "strided", "kinds", "sq_counters"):
+                fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)} of this kernel and grid): mean {sum(t) / len(t):.3f} ms\n")
+
+for name in ("phase_cfg2", "phase_cfg3", "phase_wave_1000x4", "phase_wave_500x4", "strided", "kinds"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, f"profiles/{tag}_{name}.txt")
 
 
-def rows(d, pat):
+def rows(pattern, pats):
     out = []
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if pat in r["Kernel_Name"]:
+            if any(p in r["Kernel_Name"] for p in pats):
                 out.append(r)
     return out
 
 
-def mean(d, pat):
-    v = [float(r["Counter_Value"]) for r in rows(d, pat)]
-    return sum(v) / len(v) if v else float("nan")
-
-
+# D, C, P, bytes per element, kernel, main-kernel pattern
+WORK = {"cfg2": (10000, 4, 10000, 8, "mdt_small::mdt_kernel<double>", "mdt_small"),
+        "cfg3": (100000, 8, 1000, 8, "mdt_big::mdt_kernel<double>", "mdt_big"),
+        "cfg5": (10000, 16, 12500, 4, "mdt_small::mdt_kernel<float> (mcse(mean) + rhat_nested(rank): one fused launch, mdt_mcse_nested)", "mdt_small"),
+        "cfg1": (1000, 4, 100000, 8, "mdtw::wave_kernel<double> (config 1's slice shape at scale)", "wave_kernel"),
+        "s500": (500, 4, 100000, 8, "mdtw::wave_kernel<double> (500 draws x 4 chains)", "wave_kernel")}
 cal = {}
-for d, key in (("pmc_fetch_cal", "fetch"), ("pmc_write_cal", "write")):
-    rs = [r for r in rows(d, "copy8") if int(r["Grid_Size"]) // int(r["Workgroup_Size"]) == 256 and r["Workgroup_Size"] == "1024"]
+for key in ("FETCH_SIZE", "WRITE_SIZE"):
+    rs = [r for r in rows(f"pmc_cal_{key}", ("copy8",)) if int(r["Grid_Size"]) // int(r["Workgroup_Size"]) == 256 and r["Workgroup_Size"] == "1024"]
     known_kb = 256 * 40000 * 8 * 20 / 1024
-    cal[key] = sum(float(r["Counter_Value"]) for r in rs) / len(rs) / known_kb
-WORK = {"cfg2": (10000, 4, 10000, 8, 1, "mdt_small::mdt_kernel<double>"), "cfg3": (100000, 8, 1000, 8, 1, "mdt_big::mdt_kernel<double>"),
-        "cfg5": (10000, 16, 12500, 4, 1, "mdt_small::mdt_kernel<float> (mcse(mean) + rhat_nested(rank): one fused launch, mdt_mcse_nested)")}
-out = {"calibration": {"fetch_counter_over_known": cal["fetch"], "write_counter_over_known": cal["write"],
-                       "how": "same session, tools/scatter_bench copy8 (8 B/lane coalesced, 256 WG x 1024 threads, 6.55 GB known each way)"},
-       "note": "memory-side (L2<->fabric) bytes; Infinity-Cache hits are included (upper bound on HBM traffic)"}
-for c, (D, C, P, ts, launches, kern) in WORK.items():
-    with open(f"profiles/{tag}_pmc_{c}.csv", "w") as fo:
-        w = csv.writer(fo)
-        w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
-        for d in (f"pmc_fetch_{c}", f"pmc_write_{c}"):
-            for r in rows(d, "mdt_kernel"):
-                w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
-    f_kb, w_kb = mean(f"pmc_fetch_{c}", "mdt_kernel"), mean(f"pmc_write_{c}", "mdt_kernel")
-    per_launch = f_kb * 1024 / cal["fetch"] + w_kb * 1024 / cal["write"]
-    alg = P * (D * C * ts) * launches
-    out[c] = {"draws": D, "chains": C, "params": P, "kernel": kern, "FETCH_SIZE_KB_raw_per_launch": f_kb, "WRITE_SIZE_KB_raw_per_launch": w_kb,
-              "memory_side_bytes_per_launch": per_launch, "memory_side_bytes_per_call": per_launch * launches,
-              "algorithmic_bytes_per_call": alg, "traffic_over_algorithmic": per_launch * launches / alg}
+    cal[key] = sum(float(r["Counter_Value"]) for r in rs) / len(rs) / known_kb if rs else float("nan")
 with open(f"profiles/{tag}_pmc_cal.csv", "w") as fo:
     w = csv.writer(fo)
     w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
-    for d in ("pmc_fetch_cal", "pmc_write_cal"):
-        for r in rows(d, "copy8"):
+    for key in ("FETCH_SIZE", "WRITE_SIZE"):
+        for r in rows(f"pmc_cal_{key}", ("copy8",)):
             w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
-# the file bench.py reads for roofline.traffic (headline workload)
-t2 = out["cfg2"]
-json.dump({"draws": 10000, "chains": 4, "params": 10000, "kernel": t2["kernel"], "FETCH_SIZE_KB_raw": t2["FETCH_SIZE_KB_raw_per_launch"],
-           "WRITE_SIZE_KB_raw": t2["WRITE_SIZE_KB_raw_per_launch"], "calibration": out["calibration"],
-           "hbm_bytes_per_launch": t2["memory_side_bytes_per_launch"], "profile": tag,
-           "note": out["note"] + ". Algorithmic bytes per launch: 3.2e9.", "other_workloads": {k: out[k] for k in ("cfg3", "cfg5")}},
-          open("profiles/traffic.json", "w"), indent=1)
-print(json.dumps(out, indent=1))
+
+out = {"profile": tag,
+       "calibration": {"fetch_counter_over_known": cal["FETCH_SIZE"], "write_counter_over_known": cal["WRITE_SIZE"],
+                       "how": "same session, tools/scatter_bench copy8 (8 B/lane coalesced, 256 WG x 1024 threads, 6.55 GB known each way)"},
+       "note": "memory-side (L2<->fabric) bytes, Infinity-Cache hits included (an upper bound on HBM traffic); counters are means over the launches "
+               "of the workload's main kernel in separate rocprofv3 --pmc passes (tools/collect_profiles.sh); issue floor: see bench.py",
+       "workloads": {}}
+table = []
+for c, (D, C, P, ts, kern, pat) in WORK.items():
+    cnt = {}
+    with open(f"profiles/{tag}_pmc_{c}.csv", "w") as fo:
+        w = csv.writer(fo)
+        w.writerow(["Kernel_Name", "Grid_Size", "Workgroup_Size", "Counter_Name", "Counter_Value"])
+        for r in rows(f"pmc_{c}_*", ENGINE):
+            w.writerow([r["Kernel_Name"][:60], r["Grid_Size"], r["Workgroup_Size"], r["Counter_Name"], r["Counter_Value"]])
+            if pat in r["Kernel_Name"]:
+                cnt.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in cnt.items()}
+    if not m:
+        continue
+    per_launch = m.get("FETCH_SIZE", float("nan")) * 1024 / cal["FETCH_SIZE"] + m.get("WRITE_SIZE", float("nan")) * 1024 / cal["WRITE_SIZE"]
+    alg = P * D * C * ts
+    out["workloads"][c] = {"draws": D, "chains": C, "params": P, "kernel": kern,
+                           "FETCH_SIZE_KB_raw_per_launch": m.get("FETCH_SIZE"), "WRITE_SIZE_KB_raw_per_launch": m.get("WRITE_SIZE"),
+                           "memory_side_bytes_per_launch": per_launch, "algorithmic_bytes_per_call": alg, "traffic_over_algorithmic": per_launch / alg,
+                           "valu_wave_insts": m.get("SQ_INSTS_VALU"), "salu_wave_insts": m.get("SQ_INSTS_SALU"), "lds_wave_insts": m.get("SQ_INSTS_LDS"),
+                           "vmem_rd_wave_insts": m.get("SQ_INSTS_VMEM_RD"), "vmem_wr_wave_insts": m.get("SQ_INSTS_VMEM_WR"),
+                           "mfma_wave_insts": m.get("SQ_INSTS_MFMA"), "mfma_busy_cycles": m.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+                           "valu_active_quad_cycles": m.get("SQ_ACTIVE_INST_VALU"), "wave_quad_cycles": m.get("SQ_WAVE_CYCLES"),
+                           "wait_any_quad_cycles": m.get("SQ_WAIT_ANY"), "wait_inst_any_quad_cycles": m.get("SQ_WAIT_INST_ANY"),
+                           "lds_bank_conflict_cycles": m.get("SQ_LDS_BANK_CONFLICT"), "lds_idx_active_cycles": m.get("SQ_LDS_IDX_ACTIVE"),
+                           "grbm_gui_active": m.get("GRBM_GUI_ACTIVE"), "waves": m.get("SQ_WAVES")}
+    table.append(f"== {c}: {D} x {C} x {P}, {kern}")
+    for k in sorted(m):
+        table.append(f"  {k:28s} {m[k]:.5g}  (n={len(cnt[k])})")
+    table.append(f"  memory-side bytes per launch  {per_launch:.4g}  = {per_launch / alg:.2f} x the {alg:.3g} algorithmic bytes"
+                 f"  (FETCH_SIZE / {cal['FETCH_SIZE']:.5f}, WRITE_SIZE / {cal['WRITE_SIZE']:.5f})")
+open(f"profiles/{tag}_counters.txt", "w").write("\n".join(table) + "\n")
+# the headline's entry in the old keys as well (bench.py roofline.traffic)
+if "cfg2" in out["workloads"]:
+    t2 = out["workloads"]["cfg2"]
+    out.update({"draws": 10000, "chains": 4, "params": 10000, "kernel": t2["kernel"], "hbm_bytes_per_launch": t2["memory_side_bytes_per_launch"]})
+json.dump(out, open("profiles/traffic.json", "w"), indent=1)
+print("\n".join(table))

@@ -2,6 +2,8 @@
 """Timing of the BASELINE config-3 shape (100_000 draws x 8 chains x P params Float64, FFTAutocovMethod): fused bulk+tail,
 rhat(kind=rank), ess(kind=bulk).  Usage: python tools/time_cfg3.py [P]"""
 import os, sys
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -2,6 +2,8 @@
 """Timing of the BASELINE config-5 shape (10_000 draws x 16 chains x P params Float32): mcse(kind=mean), then
 rhat_nested(kind=:rank) with superchain_ids = repeat(1:4, inner=4).  Usage: python tools/time_cfg5.py [P]"""
 import os, sys, time
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -8,6 +8,8 @@ around the launch on a raw ctypes call, nothing more than that: the kernel itsel
 (`column_moments_kernel`)."""
 import argparse
 import os
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 import sys
 import time
 

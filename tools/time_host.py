@@ -3,6 +3,8 @@
 buffer (location = MDT_HOST: the library stages it to the device, runs, copies the outputs back), pageable and pinned.
 Usage: python tools/time_host.py [P]"""
 import os, sys, time
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

@@ -2,6 +2,8 @@
 """Timing of every kind / estimator on the BASELINE config-2 shape (10_000 x 4 x P Float64), or any other.
 Usage: python tools/time_kinds.py [P [DRAWS [CHAINS]]]"""
 import os, sys, time, warnings
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np

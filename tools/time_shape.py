@@ -2,6 +2,8 @@
 """Timing of the fused bulk+tail request on any shape (needs a GPU): python tools/time_shape.py DRAWS CHAINS PARAMS [fft]
 (MDT_CONFIG / MDT_SMALL_ROUNDS / MDT_LIB in the environment select geometry and library, as everywhere.)"""
 import os, sys
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

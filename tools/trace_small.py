@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostics: kernel durations and gaps of small requests queued back to back (run under rocprofv3 --kernel-trace)."""
 import sys, time, torch
+import os as _os
+_os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
 sys.path.insert(0, "/root/repo")
 import __graft_entry__ as g
 pkg = g.load_package()
