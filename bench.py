@@ -34,9 +34,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # The library reads its test / A-B switches only behind MDT_TEST_HOOKS=1.  The bench uses two of them for the diagnostic figures
 # beside the headline (ms_no_order, the workgroup-per-parameter path beside the wave-per-parameter one); every OTHER MDT_* switch
 # is removed from the environment here, so that every reported number is the default path's whatever the caller's shell holds.
-for _k in [k for k in os.environ if k.startswith("MDT_") and k not in ("MDT_LIB", "MDT_BENCH_DRYRUN", "MDT_TEST_HOOKS")]:
-    del os.environ[_k]
-os.environ["MDT_TEST_HOOKS"] = "1"
+def _own_the_switches():
+    """(called by main(), not at import: the diagnostics under tools/ import synth / timed_ms from here and set switches of their own)"""
+    for k in [k for k in os.environ if k.startswith("MDT_") and k not in ("MDT_LIB", "MDT_BENCH_DRYRUN", "MDT_TEST_HOOKS")]:
+        del os.environ[k]
+    os.environ["MDT_TEST_HOOKS"] = "1"
 
 
 # ---------------------------------------------------------------- synthetic inputs (SURVEY.md 8d)
@@ -430,6 +432,7 @@ def main():
     ap.add_argument("--autocov", choices=("direct", "fft", "bda"), default="direct",
                     help="autocov_method of the request (BASELINE config 3 forces fft)")
     args = ap.parse_args()
+    _own_the_switches()
     if args.config4:
         args.params = 125_000
     if args.gpus < 1:

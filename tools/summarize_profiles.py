@@ -36,7 +36,7 @@ if tr:
     disp = {}
     for r in csv.DictReader(open(tr[0])):
         if any(k in r["Kernel_Name"] for k in ENGINE):
-            key = (r["Kernel_Name"][:70], r.get("Grid_Size", "?"), r.get("Workgroup_Size", "?"))
+            key = (r["Kernel_Name"][:70], r.get("Grid_Size_X", r.get("Grid_Size", "?")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "?")))
             disp.setdefault(key, []).append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
     try:
         under = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
@@ -54,7 +54,8 @@ if tr:
             d = [x[1] for x in sorted(v)]
             fo.write(f"{k[0]} grid {k[1]} wg {k[2]}: n={len(d)} mean={sum(d) / len(d):.3f} min={min(d):.3f} max={max(d):.3f}\n  "
                      + " ".join(f"{x:.2f}" for x in d[:80]) + (" ..." if len(d) > 80 else "") + "\n")
-            if under and "mdt_small" in k[0] and "double" in k[0] and k[1] == str(512 * 512) and len(d) >= under["steps"] + under["warmup"] + 3:
+            if under and "mdt_small" in k[0] and "double" in k[0] and k[1] == str(512 * 512) and len(d) >= under["steps"] + under["warmup"] + 3 and "headline_done" not in globals():
+                headline_done = True
                 # the headline's launches come first: the side-stream first call is another context (same kernel, same grid),
                 # then first request, second call, warm-up, the timed steps, then 1 + steps launches with MDT_NO_ORDER=1
                 w0 = under["warmup"] + 3
