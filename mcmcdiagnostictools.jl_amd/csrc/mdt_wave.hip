@@ -41,7 +41,9 @@ using mdtc::KP;
 
 constexpr int NS = 128;            // sample values; NS - 1 splitters
 constexpr int NCLS = 128;          // classes: #{splitters <= x}
-constexpr int WR = 512;            // members of a round (the LDS image)
+constexpr int WR = 512;            // members of a round (the LDS image).  (448 = seven rows lets a twelfth wave per CU in at 4096 values, and the extra
+                                   // rounds cost what the wave brings: 10.0 against 9.7 - 9.9 ms at 1000 x 4 x 100 000 -- measured in round 5, not kept)
+constexpr int RROWS = WR / 64;
 constexpr int NBIN = 512;          // fine bins of a round
 constexpr int MAXROUNDS = 64;
 constexpr int FT = 512;            // merged outputs of a fold tile (8 per lane)
@@ -76,7 +78,7 @@ constexpr int OFF_TAG = OFF_VAL + WR * 8;              // unsigned tag[WR]
 constexpr int OFF_BIN = OFF_TAG + WR * 4;              // unsigned short binid[WR]: bin of every slot | reserved-bin flag << 15
 constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors (read as 16-bit entries: the end of every bin)
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
-static_assert(WV_MAXN <= WR * 8, "the time-order class bytes of passes A / B live in the image");
+static_assert(WV_MAXN <= WR * 12, "the time-order class bytes of passes A / B live in the image (its values and tags)");
 // fold view
 constexpr int FE = FT + 4;                             // staged entries of a tile: for each piece the member in front of it, its members, the one behind
 constexpr int OFF_FA = OFF_VIEW;                       // double fv[FE]
@@ -96,7 +98,8 @@ constexpr int NWU_MAX = (WV_NITER + 63) / 64 + (WV_MAXLAG >> 6) + 2;
 constexpr int OFF_ICOV = OFF_VIEW;                     // double icov[2][256]
 constexpr int OFF_IMEAN = OFF_ICOV + 2 * 256 * 8;      // double imean[2][16]
 constexpr int OFF_SB2 = OFF_IMEAN + 2 * WV_MAXM * 8;   // uint64 sb2[2 m nwU] (the unfused form; the fused one sits behind the stage)
-constexpr int END_IND = OFF_SB2 + 2 * WV_MAXM * NWU_MAX * 8;
+constexpr int SB2_WORDS = 2 * (WV_MAXN / 64 + 6 * WV_MAXM);  // 2 m nwU with nwU <= niter / 64 + 6 and m niter <= WV_MAXN
+constexpr int END_IND = OFF_SB2 + SB2_WORDS * 8;
 constexpr int cmax2(int a, int b) { return a > b ? a : b; }
 constexpr int PERWAVE = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER, END_IND)) + 15) / 16) * 16;
 constexpr int VIEW_BYTES = PERWAVE - OFF_VIEW;
@@ -535,8 +538,8 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     unsigned anyodd = 0u;
     // members of round r: one contiguous piece [g0, g1) of the class-sorted scratch; the next round's loads are issued as soon
     // as this round's members sit in the LDS image (their registers are free then)
-    double v[8];
-    unsigned tg[8];
+    double v[RROWS];
+    unsigned tg[RROWS];
     auto round_span = [&](unsigned r, unsigned& cA, unsigned& cB, unsigned& g0, unsigned& g1) {
         cA = rflu((unsigned)rtab[r]); cB = rflu((unsigned)rtab[r + 1]);
         g0 = cA ? rflu(ccur[cA - 1u]) : 0u;
@@ -547,7 +550,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         round_span(r, cA, cB, g0, g1);
         const unsigned M = g1 - g0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RROWS; ++i) {
             const unsigned idx = 64u * i + (unsigned)lane;
             const unsigned src = g0 + (idx < M ? idx : 0u);
             const Rec rc = rec_load(rec + (src < n ? src : n - 1u));
@@ -565,13 +568,13 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         const double fsub = (double)((1u << sh) - 1u), fcap = (double)((1u << sh) - 2u);
 #pragma unroll
         for (int q = 0; q < NBIN / 2 / 64; ++q) cnt[lane + 64 * q] = 0u;
-        unsigned bn[8];
+        unsigned bn[RROWS];
         {
-            double lo[8], wd[8];
+            double lo[RROWS], wd[RROWS];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = iw[cls]; }
+            for (int i = 0; i < RROWS; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = iw[cls]; }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RROWS; ++i) {
                 // piecewise-linear fine bin inside the class; sub-bin 0 = equal to the class's lower bound (a constant bin)
                 const unsigned cls = tg[i] >> 24;
                 double f = (v[i] - lo[i]) * wd[i] * fsub;
@@ -581,7 +584,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RROWS; ++i) {
             const unsigned b = bn[i] & 0x7FFFu;
             if (64u * i + (unsigned)lane < M) lds_add(&cnt[b >> 1], 1u << ((b & 1u) << 4));
         }
@@ -600,7 +603,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         lds_fence();
         WPROF(11);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RROWS; ++i) {
             if (64u * i + (unsigned)lane < M) {
                 const unsigned b = bn[i] & 0x7FFFu, shb = (b & 1u) << 4;
                 const unsigned pos = (lds_add(&cnt[b >> 1], 1u << shb) >> shb) & 0xFFFFu;
@@ -1134,7 +1137,7 @@ WV_PHASE void ph_indicators(unsigned wbase_arg) {
     WV_LA unsigned long long* sb2 = (WV_LA unsigned long long*)(wb + OFF_SB2);
     if (have) { // the words the series phase took sit behind its stage, where this phase's tables go: move them (through registers)
         const WV_LA unsigned long long* src = (const WV_LA unsigned long long*)((WV_LA double*)(wb + OFF_STG) + stg_doubles);
-        constexpr int NWL = (2 * WV_MAXM * NWU_MAX + 63) / 64;
+        constexpr int NWL = (SB2_WORDS + 63) / 64;
         unsigned long long tmp[NWL];
 #pragma unroll
         for (int q = 0; q < NWL; ++q) { const int i = lane + 64 * q; tmp[q] = (i < 2 * m * nwU) ? src[i] : 0ull; }
@@ -1397,11 +1400,15 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
 }
 
 // ------------------------------------------------------------------ host side
+static int g_debug_waves = 0;
+void set_debug_waves(int w) { g_debug_waves = w; }
+
 Geo geometry(long long n, int f32) {
     Geo g;
     g.tab_bytes = (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16);
     int wv = (LDS_TOTAL - g.tab_bytes) / PERWAVE;
     if (wv > NTHREADS / 64) wv = NTHREADS / 64;
+    if (g_debug_waves > 0 && g_debug_waves < wv) wv = g_debug_waves; // diagnostics (MDT_WAVE_WAVES): fewer waves per workgroup
     if (wv < 1) wv = 1;
     g.waves = wv;
     g.lds_bytes = g.tab_bytes + wv * PERWAVE;
