@@ -576,6 +576,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
 #pragma unroll
             for (int i = 0; i < RROWS; ++i) {
                 // piecewise-linear fine bin inside the class; sub-bin 0 = equal to the class's lower bound (a constant bin)
+                // (skipping the rows a round does not fill -- scalar branches -- was measured neutral, round 5)
                 const unsigned cls = tg[i] >> 24;
                 double f = (v[i] - lo[i]) * wd[i] * fsub;
                 f = f < fcap ? f : fcap;
@@ -922,7 +923,8 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
 // the same bits); centred; lag products (src/ess_rhat.jl:170-178) as blocked Hankel tiles on v_mfma_f64_16x16x4_f64,
 // accumulated over the chains; Geyer's initial monotone sequence (:555-594) between blocks of 32 lags.  While a chain is
 // staged its tail-ESS indicator words are taken from the ranks (x <= q <=> doubled rank <= r2q).
-WV_PHASE void ph_series(unsigned wbase_arg) {
+// (NB: rows of 64 draws the code is unrolled for -- 4, 8 or 10: the kernel picks the smallest that holds a split chain)
+template <typename T, int NB> __device__ __attribute__((noinline)) void ph_series(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* lagA = (WV_LA double*)(wb + OFF_LAGA);
     WV_LA double* mean_j = (WV_LA double*)(wb + OFF_MEAN);
@@ -957,7 +959,6 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
     bool started = false, done = false;
     long long k0 = 0;
     int block = 0;
-    constexpr int NB = (WV_NITER + 63) / 64;
     unsigned rn[NB];
     auto issue = [&](int j) { // the rank list of split chain j: all its rows in flight
         const WV_GA unsigned* rj = rl + (unsigned)j * niter;
@@ -1119,7 +1120,7 @@ WV_PHASE void ph_series(unsigned wbase_arg) {
 // The indicator words of every split chain (from the ranks while the chain was staged, else built here from the ranks or from
 // x itself), per chain and lag sum I_t I_{t+k} = popcount(bits & bits >> k), centred exactly in int64, lanes = 16 lags x 4
 // word segments; lanes 0 / 1 run Geyer's scan of the two indicators between blocks of 16 lags.
-WV_PHASE void ph_indicators(unsigned wbase_arg) {
+template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indicators(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* icov = (WV_LA double*)(wb + OFF_ICOV);
     WV_LA double* imean = (WV_LA double*)(wb + OFF_IMEAN);
@@ -1151,7 +1152,6 @@ WV_PHASE void ph_indicators(unsigned wbase_arg) {
         const T qloT = (T)rfld(ws->qlo), qhiT = (T)rfld(ws->qhi);
         for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull;
         lds_fence();
-        constexpr int NB = (WV_NITER + 63) / 64;
         for (int j = 0; j < m; ++j) {
             const unsigned c = (unsigned)j / s, k = (unsigned)j - c * s;
             unsigned long long q0[NB], q1[NB];
@@ -1369,9 +1369,18 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
                     if (kp.need_rt) { ph_fold<T>(wbase); fb = rfl(ws->fallback) != 0; }
                     WDBG(50);
                     if (!fb && stop != 4) {
-                        if (kp.need_eb || kp.need_rb) ph_series<T>(wbase);
+                        const unsigned nblk = ((unsigned)kp.niter + 63u) >> 6;
+                        if (kp.need_eb || kp.need_rb) {
+                            if (nblk <= 4u) ph_series<T, 4>(wbase);
+                            else if (nblk <= 8u) ph_series<T, 8>(wbase);
+                            else ph_series<T, (WV_NITER + 63) / 64>(wbase);
+                        }
                         WDBG(60);
-                        if (kp.need_et && kp.ess_ok && stop != 5) ph_indicators<T>(wbase);
+                        if (kp.need_et && kp.ess_ok && stop != 5) {
+                            if (nblk <= 4u) ph_indicators<T, 4>(wbase);
+                            else if (nblk <= 8u) ph_indicators<T, 8>(wbase);
+                            else ph_indicators<T, (WV_NITER + 63) / 64>(wbase);
+                        }
                     }
                 }
             }
