@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Soak test (needs a GPU; not part of the pytest suite): random shapes up to ~150 000 values per slice, splits,
-kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many|order]
+kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many|order|wave]
 (long: chains of 50 000 - 131 072 draws, maxlag up to 1000; many: 100 - 1500 chains, more split chains than the LDS moment tables hold;
 order: 600 - 4000 short parameters per request, each request issued twice -- the second launch hands its tickets out by
-the costs the first one measured.  Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
+the costs the first one measured; wave: slices of 256 ... 4096 values in up to 16 split chains, 1 - 300 parameters per request, the
+geometry never forced: the wave-per-parameter kernel of round 5 and, for what it hands back, the general kernel behind it.
+Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
 import os, sys, time, warnings
 import os as _os
 _os.environ.setdefault("MDT_TEST_HOOKS", "1")  # diagnostics: the library reads its A/B switches only behind this gate
@@ -21,6 +23,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 LONG = len(sys.argv) > 3 and sys.argv[3] == "long"
 MANY = len(sys.argv) > 3 and sys.argv[3] == "many"
 ORDER = len(sys.argv) > 3 and sys.argv[3] == "order"
+WAVE = len(sys.argv) > 3 and sys.argv[3] == "wave"
 methods = {"direct": pkg.AutocovMethod(), "fft": pkg.FFTAutocovMethod(), "bda": pkg.BDAAutocovMethod()}
 
 
@@ -73,6 +76,10 @@ while time.time() - t0 < budget:
     if ORDER:  # many short parameters: more tickets than workgroups, the second launch is cost-ordered
         D, C, P = int(rng.integers(20, 400)), int(rng.integers(1, 5)), int(rng.integers(600, 4000))
     s = int(rng.integers(1, 4))
+    if WAVE:
+        C = int(rng.integers(1, 9))
+        D = int(rng.integers(max(8 * s, (256 + C - 1) // C), 4096 // C + 1))
+        P = int(rng.choice([1, 3, 17, 300]))
     if it % 2:
         os.environ["MDT_PA"] = "2"
     else:
@@ -101,7 +108,7 @@ while time.time() - t0 < budget:
     tol = 5e-6 if f32 else 1e-8
     ml = int(rng.choice([1, 7, 100, 250, 600, 1000] if LONG else [1, 7, 100, 250]))  # (long chains: the lag tiles of the windowed series up to the cap)
     m = ("direct", "fft", "bda")[it % 3]
-    cfg = ("", "", "small", "big", "tiny")[it % 5]
+    cfg = "" if WAVE else ("", "", "small", "big", "tiny")[it % 5]
     if cfg:
         os.environ["MDT_CONFIG"] = cfg
     else:
