@@ -319,7 +319,7 @@ def other_configs(pkg, device, steps, warmup):
         xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
         want = c_oracle.bulk_tail(xs)
         b_alg = D * C * 8 + 4 * 8
-        wave = D * C <= 4096
+        wave = D * C <= 8192 and D // 2 <= 640 and 2 * C <= 16
         extra = {}
         if wave:  # the same request on the workgroup-per-parameter kernels (what served it until round 4), beside it
             os.environ["MDT_WAVE"] = "0"
@@ -354,7 +354,7 @@ def other_configs(pkg, device, steps, warmup):
 
 def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
     """the fused bulk+tail request over draws x chains shapes at ~1.6 GB of Float64 each: every boundary between the paths
-    (wave-per-parameter kernel up to 4096 values per slice, 256- / 512-thread workgroups per parameter beyond) is visible
+    (wave-per-parameter kernel up to 8192 values per slice in split chains of at most 640 draws, 256- / 512-thread workgroups per parameter beyond) is visible
     in the driver's record"""
     rows = []
     for D in (250, 500, 1_000, 2_000, 5_000, 10_000):
@@ -367,7 +367,7 @@ def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
             b_alg = D * C * 8 + 4 * 8
             rows.append({"draws": D, "chains": C, "params": P, "ms": round(ms, 3), "param_series_per_s": round(P / (ms * 1e-3), 1),
                          "hbm_frac": round(P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "path": "wave" if D * C <= 4096 and D // 2 <= 640 else ("wg256" if D * C <= 12288 and D // 2 <= 1392 else "wg512")})
+                         "path": "wave" if D * C <= 8192 and D // 2 <= 640 and 2 * C <= 16 else ("wg256" if D * C <= 12288 and D // 2 <= 1392 else "wg512")})
             del x, x_pcd, outs
             torch.cuda.empty_cache()
     return {"note": "bulk+tail, split_chains 2, maxlag 250, ~1.6 GB of Float64 per shape, 3 timed steps after 1 warm-up; path = which kernel "

@@ -8,7 +8,7 @@
 namespace mdtw {
 
 // limits of the path (everything else is served by the workgroup-per-parameter kernels of mdt_device.hpp)
-constexpr int WV_MAXN = 4096;     // draws * chains
+constexpr int WV_MAXN = 8192;     // draws * chains
 constexpr int WV_MAXM = 16;       // chains * split_chains
 constexpr int WV_NITER = 640;     // draws / split_chains
 constexpr int WV_MAXLAG = 255;    // effective maxlag

@@ -5,7 +5,7 @@
 // few dependent LDS or L2 round trips: 2.6 % of the HBM roof at 1000 x 4, 1.5 % at 500 x 4.  Here a
 // wave64 owns a parameter from its ticket to its four outputs and synchronises with nobody: waves of a CU drift apart, and
 // whenever one waits for memory or the LDS the others issue.  What makes that possible is that nothing of the size of the
-// slice lives in LDS: a wave holds ~11 KB (one ROUND of the ranking, one fold tile, one split chain), the slice itself
+// slice lives in LDS: a wave holds ~12 KB (one ROUND of the ranking, one fold tile, one split chain), the slice itself
 // passes through a per-wave scratch in global memory that stays in the L2 / Infinity Cache, and the normal-score table of
 // the shape (src/utils.jl:182, 189-193) is shared by the waves of a workgroup, read-only, in LDS.
 //
@@ -78,7 +78,7 @@ constexpr int OFF_TAG = OFF_VAL + WR * 8;              // unsigned tag[WR]
 constexpr int OFF_BIN = OFF_TAG + WR * 4;              // unsigned short binid[WR]: bin of every slot | reserved-bin flag << 15
 constexpr int OFF_CNT = OFF_BIN + WR * 2;              // unsigned cnt[NBIN / 2]: packed 16-bit counters, then cursors (read as 16-bit entries: the end of every bin)
 constexpr int END_RANK = OFF_CNT + NBIN * 2;
-static_assert(WV_MAXN <= WR * 12, "the time-order class bytes of passes A / B live in the image (its values and tags)");
+static_assert(WV_MAXN <= END_RANK - OFF_VAL, "the time-order class bytes of passes A / B live in the bytes of the round tables");
 // fold view
 constexpr int FE = FT + 4;                             // staged entries of a tile: for each piece the member in front of it, its members, the one behind
 constexpr int OFF_FA = OFF_VIEW;                       // double fv[FE]

@@ -1529,7 +1529,7 @@ def _wave_case_array(rng):
 
 
 def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
-    """Round 5: slices of 256 ... 4096 values run ONE PARAMETER PER WAVE (csrc/mdt_wave.hip): no workgroup barrier, the slice
+    """Round 5: slices of 256 ... 8192 values run ONE PARAMETER PER WAVE (csrc/mdt_wave.hip): no workgroup barrier, the slice
     class-sorted through a per-wave scratch, ranked round by round in ~11 KB of LDS, fold merge, z-series staged per split
     chain, lag products on the matrix pipe, popcount indicators.  MDT_WAVE=0 sends the same request down the
     workgroup-per-parameter kernels: R-hat must be the same BITS (same fixed-point moments, same expressions), ESS within
@@ -1541,7 +1541,8 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
     x = _wave_case_array(rng)
     shapes = [("1000x4", x), ("997x4", x[:997]), ("500x4", x[:500]), ("250x4", x[:250]), ("64x4", x[:64]), ("f32", x.astype(np.float32)),
               ("640x6", np.concatenate([x[:640], x[:640, :2]], axis=1)), ("250x8", np.concatenate([x[:250], x[250:500]], axis=1)),
-              ("1000x1", x[:, :1]), ("1280x3", np.concatenate([x, x[:280]], axis=0)[:, :3])]
+              ("1000x1", x[:, :1]), ("1280x3", np.concatenate([x, x[:280]], axis=0)[:, :3]),
+              ("1000x8", np.concatenate([x, x[::-1]], axis=1)), ("1280x6", np.concatenate([np.concatenate([x, x[:280]], axis=0), np.concatenate([x[::-1], x[:280]], axis=0)[:, :2]], axis=1))]
 
     def run_all(xd, s):
         out = []
@@ -1561,7 +1562,7 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
     for what, xs in shapes:
         for s in (2, 1, 3):
             D, C = xs.shape[:2]
-            if C * s > 16 or D // s > 640 or D // s < 8 or D * C < 256:
+            if C * s > 16 or D // s > 640 or D // s < 8 or D * C < 256 or D * C > 8192:
                 continue
             xd = dev(xs)
             monkeypatch.setenv("MDT_WAVE", "2")
