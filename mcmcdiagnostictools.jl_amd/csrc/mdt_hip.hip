@@ -618,8 +618,12 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // FFTAutocovMethod (evaluated from lag products, as everywhere).  Parameters it cannot serve (a NaN, an infinity, a point mass
     // larger than a round, many ties among the folded values) come back in a list and the general kernel, queued behind it, works
     // that list off.  MDT_WAVE=0: never, 2: wherever it can run (tests, A/B timing; needs MDT_TEST_HOOKS=1 like every switch)
+    // A wave works on its parameter for 0.1 - 0.4 ms where a workgroup needs 0.04 - 0.08: the wave kernel wins once there are enough
+    // parameters to keep its ~3000 waves busy for a few tickets each, and loses below -- measured crossover (fused bulk+tail):
+    // 1000 x 4 at ~6000 parameters (P = 10: 0.31 against 0.12 ms), 250 x 4 at ~2000.  Hence the parameter count in the rule.
     const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
-    const bool wave = wave_env != 0 && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
+    const bool wave_pays = P >= 700 + (4 * n) / 3;
+    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
                       (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) &&
                       n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER &&
                       maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&

@@ -55,7 +55,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "quick":
     sys.exit(0)
 for (D, C, P) in [(1000, 4, 100000), (500, 4, 100000), (250, 4, 200000), (1000, 2, 100000), (600, 6, 60000)]:
     x = synth(D, C, P, torch.device("cuda", 0), 4321).permute(2, 1, 0)
-    for wv in ("1", "0"):
+    for wv in ("2", "0"):
         os.environ["MDT_WAVE"] = wv
         ms = timed_ms(lambda: pkg.bulk_tail(x, sync=False), 5, 2)
         print(f"{D}x{C}x{P} MDT_WAVE={wv}: bulk+tail {ms:.2f} ms  ({D*C*P*8/ms/1e6:.0f} GB/s of input)  status {pkg.status()}")

@@ -77,6 +77,7 @@ while time.time() - t0 < budget:
         D, C, P = int(rng.integers(20, 400)), int(rng.integers(1, 5)), int(rng.integers(600, 4000))
     s = int(rng.integers(1, 4))
     if WAVE:
+        os.environ["MDT_WAVE"] = "2"  # (the default takes the wave kernel only from a few thousand parameters on)
         C = int(rng.integers(1, 9))
         D = int(rng.integers(max(8 * s, (256 + C - 1) // C), min(640 * s, 8192 // C) + 1))
         P = int(rng.choice([1, 3, 17, 300]))
