@@ -590,7 +590,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // tables -- phases of two parameters overlap on every CU; one 1024-thread workgroup per CU otherwise
     const bool fft_lds = fft && hook("MDT_FFT_LDS") != nullptr; // run the in-LDS transform instead of lagged products (tests)
     const bool small_fits = maxlag <= mdt_small::MAXLAG_CAP && (!fft_lds || niter + maxlag + 1 <= mdt_small::FFT_MAXN) &&
-                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH * (hook("MDT_SMALL_ROUNDS") ? atoll(hook("MDT_SMALL_ROUNDS")) : 64);
+                            niter <= (long long)mdt_small::BITW * 64 && n <= (long long)mdt_small::QCH8 * (hook("MDT_SMALL_ROUNDS") ? atoll(hook("MDT_SMALL_ROUNDS")) : 64);
     // short slices: four 256-thread workgroups per CU (40 KiB of LDS each) -- a parameter of a few thousand values
     // is mostly barrier and latency chains, which twice as many resident workgroups hide twice as well
     int force_cfg = ctx->force_cfg; // MDT_CONFIG is honoured per request (tests switch it between calls)
@@ -608,7 +608,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // per-parameter latency chains better than two large ones.  MDT_ONECHUNK=0: never, 2: wherever it can run (tests, A/B timing)
     const int oc_env = hook("MDT_ONECHUNK") ? atoi(hook("MDT_ONECHUNK")) : 1;
     const bool onechunk = oc_env != 0 && small_fits && rq.mode == 0 && !rq.basic &&
-                          rq.est == 0 && n <= (long long)mdt_small::OC_MAX && (oc_env == 2 || n > (long long)mdt_tiny::QCH) && D % s == 0 && m <= 8 &&
+                          rq.est == 0 && n <= (long long)mdt_small::OC_MAX && (oc_env == 2 || n > (long long)mdt_tiny::QCH8) && D % s == 0 && m <= 8 &&
                           niter >= 64 && !fft_lds && niter + maxlag + 80 <= mdt_small::SZ && maxlag < mdt_small::SZ_EDGE &&
                           (rq.need_eb || rq.need_rb) && !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2);
     const bool tiny = force_cfg == 0 ? (tiny_fits && !onechunk) : (force_cfg == 3 && tiny_fits);
@@ -620,9 +620,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // that list off.  MDT_WAVE=0: never, 2: wherever it can run (tests, A/B timing; needs MDT_TEST_HOOKS=1 like every switch)
     // A wave works on its parameter for 0.1 - 0.4 ms where a workgroup needs 0.04 - 0.08: the wave kernel wins once there are enough
     // parameters to keep its ~3000 waves busy for a few tickets each, and loses below -- measured crossover (fused bulk+tail):
-    // 1000 x 4 at ~6000 parameters (P = 10: 0.31 against 0.12 ms), 250 x 4 at ~2000.  Hence the parameter count in the rule.
+    // 1000 x 4 at ~6000 parameters (P = 10: 0.31 against 0.12 ms), 500 x 4 at ~4000, 250 x 4 at ~2000; above 4096 values the score
+    // table leaves room for 8 waves per CU and the crossover moves out (1000 x 8: 16 000 parameters 5.2 against 4.9 ms, 50 000: 13.5
+    // against 14.6).  Hence the parameter count in the rule.
     const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
-    const bool wave_pays = P >= 700 + (4 * n) / 3;
+    const bool wave_pays = P >= (n > 4096 ? 3 * n : 700 + (4 * n) / 3);
     const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
                       (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) &&
                       n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER &&
@@ -789,7 +791,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         kp.rank_variant = rv ? atoi(rv) : 2;
         // the round tables hold MAXROUNDS rounds of at most one LDS chunk each: beyond that the ranking cannot be served
         // (slices between half of that and that may still overflow on the device: status flag, NaN outputs)
-        const long long chunk = tiny ? std::min(mdt_tiny::QCH, mdt_tiny::CH) : (small ? std::min(mdt_small::QCH, mdt_small::CH) : std::min(mdt_big::QCH, mdt_big::CH));
+        const long long chunk = tiny ? std::min(mdt_tiny::QCH8, mdt_tiny::CH) : (small ? std::min(mdt_small::QCH8, mdt_small::CH) : std::min(mdt_big::QCH8, mdt_big::CH));
         if (need_rank && n > (long long)mdt_big::MAXROUNDS * chunk)
             return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large for the on-chip ranking (round table overflow)");
     }
