@@ -13,6 +13,13 @@ if [ -f tools/exp/libwaveprof.so ]; then
   MDT_LIB=$R/tools/exp/libwaveprof.so python tools/dev_wave_prof.py 1000 4 100000 2>/dev/null | grep -v amdgpu.ids > $O/phase_wave_1000x4.txt
   MDT_LIB=$R/tools/exp/libwaveprof.so python tools/dev_wave_prof.py 500 4 100000 2>/dev/null | grep -v amdgpu.ids > $O/phase_wave_500x4.txt
 fi
+if [ -f tools/exp/libprofq.so ]; then  # (tools/build_variant.sh profq -DMDT_PROF_Q: the sub-slots of the ranking)
+  MDT_LIB=$R/tools/exp/libprofq.so python tools/phase_profile.py --cfg5 --q --params 12500 2>/dev/null | grep -v amdgpu.ids > $O/phase_cfg5_rank.txt
+fi
+python tools/time_cfg5.py 12500 2>/dev/null | tail -1 > $O/cfg5_split.txt
+# where the wave-per-parameter kernel starts to pay: default rule (1), forced (2), never (0)
+for sh in "1000 4" "500 4" "250 4" "1000 8"; do for P in 1000 2000 4000 8000 16000 32000; do for w in 1 2 0; do
+  echo -n "MDT_WAVE=$w "; MDT_TEST_HOOKS=1 MDT_WAVE=$w python tools/time_shape.py $sh $P 2>/dev/null | tail -1 | cut -c1-48; done; done; done > $O/wave_crossover.txt
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
