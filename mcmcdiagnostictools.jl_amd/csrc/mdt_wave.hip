@@ -487,7 +487,8 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
             const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
             if (r < NRW && ra_.d < D) {
                 const unsigned pos = lds_add(&ccur[cl[u]], 1u);
-                unsigned k = 0u;
+                unsigned k = 0u; // (s - 1 steps, usually one: kept from the loop vectoriser, which interleaved it by two behind a remainder loop)
+#pragma clang loop vectorize(disable) interleave(disable)
                 for (unsigned kk = 1u; kk < s; ++kk) k += (ra_.d >= row0(kk)) ? 1u : 0u;
                 const unsigned c = (r < NRW ? r : NRW - 1u) / rpc;
                 const unsigned slot = (ra_.d < row0(k) + niter) ? c * s + k : 255u; // (255: a row the split drops)
