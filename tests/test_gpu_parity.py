@@ -1636,6 +1636,38 @@ print(json.dumps([o.cpu().numpy().tolist() for o in pkg.bulk_tail(xd)]))
     assert outs[0] == outs[1]
 
 
+def test_wave_path_is_taken_from_the_parameter_count_at_which_it_pays(pkg, monkeypatch):
+    """The host takes the wave-per-parameter kernel only when the request has enough parameters to fill it (params >=
+    700 + 4/3 draws x chains; below, a workgroup per parameter has the lower latency).  The two families agree in R-hat bit for
+    bit and in ESS to ~1e-15 only, so the bits tell which one ran: 300 x 4 slices (threshold 2300 parameters) -- 200 parameters
+    must be the bits of MDT_WAVE=0, 3000 those of MDT_WAVE=2 (and not those of MDT_WAVE=0: the ESS of some parameter differs in
+    its last bits)."""
+    rng = np.random.default_rng(2300)
+    x = ar1(0.5, 300, 4, 3000, rng)
+    xd = dev(x)
+
+    def run(P, wave):
+        if wave is None:
+            monkeypatch.delenv("MDT_WAVE", raising=False)
+        else:
+            monkeypatch.setenv("MDT_WAVE", wave)
+        return [o.cpu().numpy() for o in pkg.bulk_tail(xd[:, :, :P])]  # (the first P parameters: a dense block of the same array)
+
+    few_default, few_never, few_forced = run(200, None), run(200, "0"), run(200, "2")
+    many_default, many_never, many_forced = run(3000, None), run(3000, "0"), run(3000, "2")
+    for a, b in zip(few_default, few_never):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(many_default, many_forced):
+        np.testing.assert_array_equal(a, b)
+    # R-hat: the same bits whichever kernel; ESS: the families sum the lag products in another order
+    for i in (2, 3):
+        np.testing.assert_array_equal(many_forced[i], many_never[i])
+        np.testing.assert_array_equal(few_forced[i], few_never[i])
+    assert any(not np.array_equal(many_forced[i], many_never[i]) for i in (0, 1)), "the forced paths gave identical ESS bits: the test cannot tell them apart"
+    for i in (0, 1):
+        np.testing.assert_allclose(many_forced[i], many_never[i], rtol=1e-12)
+
+
 def test_chain_lengths_between_the_lds_resident_and_the_windowed_series(pkg, methods):
     """Split chains of SZ - 80 ... SZ - 41 draws (SZ = 6400 doubles of chain buffer in the 512-thread geometry) were neither
     `zfast` (chain resident in LDS) nor `long_chain` (windowed series) until round 4 -- two margins, 80 and 40 -- and took the
