@@ -1668,6 +1668,35 @@ def test_wave_path_is_taken_from_the_parameter_count_at_which_it_pays(pkg, monke
         np.testing.assert_allclose(many_forced[i], many_never[i], rtol=1e-12)
 
 
+def test_reserve_changes_no_bits_and_validates_like_a_request(pkg):
+    """mdt_ctx_reserve (C-ABI 0.3.1; include/mdt_hip.h): announcing the shape moves the allocations and the score table out of the
+    first request -- and nothing else: a request on a fresh stream (= a fresh context) with and without the announcement gives
+    the same bits, for a shape of each kernel family, Float64 and Float32; a shape nobody can serve is refused as a request would
+    refuse it."""
+    import torch
+    rng = np.random.default_rng(31)
+    for (D, C, P), dt in (((1000, 4, 40), np.float64), ((10000, 4, 6), np.float64), ((500, 8, 24), np.float32)):
+        x = ar1(0.4, D, C, P, rng).astype(dt)
+        outs = []
+        for announce in (False, True):
+            st = torch.cuda.Stream()  # the context cache is keyed by (device, stream): nothing allocated yet on this one
+            with torch.cuda.stream(st):
+                xd = dev(x)
+                if announce:
+                    pkg.reserve(D, C, P, dtype=dt)
+                    pkg.reserve(D, C, P, dtype=dt)  # (idempotent)
+                outs.append([o.cpu().numpy() for o in pkg.bulk_tail(xd)])
+            st.synchronize()
+        for a, b in zip(*outs):
+            np.testing.assert_array_equal(a, b)
+    with pytest.raises(pkg.ArgumentError):
+        pkg.reserve(100, 4, 10, dtype=np.int32)
+    with pytest.raises(pkg.DimensionMismatch):
+        pkg.reserve(0, 4, 10)
+    with pytest.raises(Exception):
+        pkg.reserve(1 << 20, 1 << 11, 1)  # draws x chains beyond the ranking's index range
+
+
 def test_chain_lengths_between_the_lds_resident_and_the_windowed_series(pkg, methods):
     """Split chains of SZ - 80 ... SZ - 41 draws (SZ = 6400 doubles of chain buffer in the 512-thread geometry) were neither
     `zfast` (chain resident in LDS) nor `long_chain` (windowed series) until round 4 -- two margins, 80 and 40 -- and took the
