@@ -1612,6 +1612,28 @@ def test_wave_path_on_the_golden_vectors(pkg, methods, monkeypatch, name):
         assert_close(host(R), g[kr], RTOL64, f"{name} {kr}")
 
 
+def test_wave_path_strided_and_host_inputs(pkg, monkeypatch):
+    """MCMCChains storage read in place (chain_stride / param_stride) and host arrays through the wave-per-parameter kernel:
+    the same bits as the dense device call on the same kernel."""
+    import torch
+    monkeypatch.setenv("MDT_WAVE", "2")
+    rng = np.random.default_rng(19)
+    for dt in (np.float64, np.float32):
+        for shape in ((300, 4, 7), (1000, 4, 9), (640, 6, 5)):
+            x = (ar1(0.6, *shape, rng) + 0.1 * rng.standard_normal(shape)).astype(dt)
+            store = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 2, 0)))).cuda()  # (chains, params, draws) C-order
+            view = store.permute(2, 0, 1)
+            assert view.stride() == (1, shape[0] * shape[2], shape[0])
+            dense = pkg.bulk_tail(dev(x))
+            for u, w in zip(pkg.bulk_tail(view), dense):
+                assert np.array_equal(host(u), host(w), equal_nan=True)
+            for u, w in zip(pkg.bulk_tail(x), dense):                                         # host array in, host arrays out
+                assert np.array_equal(np.asarray(u), host(w), equal_nan=True)
+            for kind in ("bulk", "tail", "rank"):
+                a, b = pkg.ess_rhat(view, kind=kind), pkg.ess_rhat(dev(x), kind=kind)
+                assert np.array_equal(host(a.ess), host(b.ess)) and np.array_equal(host(a.rhat), host(b.rhat))
+
+
 def test_switches_need_the_test_hooks_gate(pkg):
     """The library reads MDT_WAVE, MDT_CONFIG, MDT_RANK_VARIANT ... only when MDT_TEST_HOOKS=1 was set when it was first used
     (tests/conftest.py does that): a child process WITHOUT the gate must give the default path's bits whatever the switches say."""
