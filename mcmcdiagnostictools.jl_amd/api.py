@@ -19,6 +19,7 @@ diagnostic on the CPU.
 """
 import ctypes
 import statistics
+import sys
 import warnings
 from collections import namedtuple
 
@@ -116,7 +117,10 @@ def _prepare(samples, allow_strided=False):
         return _prepare_shards(samples)
     pr = _Prepared()
     mask = None
-    if isinstance(samples, np.ma.MaskedArray):  # the reference's Union{Missing,T} eltype
+    # the reference's Union{Missing,T} eltype.  (numpy imports numpy.ma on first touch -- 40 - 55 ms, measured as most of a process's
+    # first request -- and an array can only be a MaskedArray if somebody has imported it already)
+    ma = sys.modules.get("numpy.ma")
+    if ma is not None and isinstance(samples, ma.MaskedArray):
         mask = np.ma.getmaskarray(samples)
         samples = samples.filled(0.0)
     is_torch = torch is not None and isinstance(samples, torch.Tensor)
