@@ -676,6 +676,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     int wave_wgs = 0;
     if (wave) {
         mdtw::set_debug_waves(hook("MDT_WAVE_WAVES") ? atoi(hook("MDT_WAVE_WAVES")) : 0);
+        mdtw::set_tab_mode(hook("MDT_WAVE_TAB") ? atoi(hook("MDT_WAVE_TAB")) : 0);
         wgeo = mdtw::geometry(n, f32 ? 1 : 0);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         wave_wgs = (int)std::min<long long>(ncu, (P + wgeo.waves - 1) / wgeo.waves);

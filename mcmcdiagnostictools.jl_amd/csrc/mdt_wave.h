@@ -25,6 +25,7 @@ Geo geometry(long long n, int f32);
 size_t scratch_bytes(const Geo& g, long long waves_total);
 void set_debug_buf(unsigned* host_pinned); // diagnostics: progress word per wave
 void set_debug_waves(int w); // diagnostics: at most w waves per workgroup (0 = what the LDS allows)
+void set_tab_mode(int t);    // diagnostics: 0 the rule, 1 score table always in LDS, 2 never
 void set_debug_stop(int k); // diagnostics: parameters end after phase k (0 = never)
 int prepare_device(); // once per device, under its hipSetDevice: 0 = ok
 // Queue the kernel on `st`: workgroups x waves tickets over kp->P parameters.  `kp_slot` is the device copy of the parameter

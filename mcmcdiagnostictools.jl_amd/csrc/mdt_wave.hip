@@ -151,6 +151,7 @@ struct WS {
     unsigned r2q[2];                  // x <= q  <=>  doubled rank <= r2q (when zq_ok)
     int fallback, zq_ok, bits_done, stop;
     unsigned lz, gw;                  // LDS address of the score table; global wave index
+    unsigned tab_lds;                 // the score table of whole ranks sits in LDS (else: read from the global copy)
 };
 static_assert(sizeof(WS) <= WS_BYTES, "wave state block");
 #define WV_LA __attribute__((address_space(3)))
@@ -936,6 +937,8 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
     WV_LA double* stage = (WV_LA double*)(wb + OFF_STG);
     typedef xs_of<T> ZT_t;
     const WV_LA ZT_t* lz = (const WV_LA ZT_t*)(unsigned long long)rflu(ws->lz);
+    const bool tab_lds = rflu(ws->tab_lds) != 0u;
+    const WV_GA ZT_t* gzd_s = (const WV_GA ZT_t*)kp.ztab + (2u * (unsigned)kp.n + 1u);
     const WV_GA ZT_t* gz = (const WV_GA ZT_t*)kp.ztab;
     const WV_GA unsigned* rl = (const WV_GA unsigned*)rfl64(ws->ra);
     const unsigned niter = (unsigned)kp.niter;
@@ -1001,6 +1004,10 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
             double z[NB];
 #pragma unroll
             for (int b = 0; b < NB; ++b) z[b] = (double)lz[r2[b] >> 1];
+            if (!tab_lds) { // (the shape's table is not in LDS: the same entries from the dense global copy, L2)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) z[b] = (double)gzd_s[r2[b] >> 1];
+            }
             if (anyodd) { // a half-integer rank: the table by doubled rank
 #pragma unroll
                 for (int b = 0; b < NB; ++b) if (r2[b] & 1u) z[b] = (double)gz[r2[b]];
@@ -1319,7 +1326,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
     {
         ZT_t* lz = (ZT_t*)smem;
         const WV_GA ZT_t* gzd = (const WV_GA ZT_t*)kp.ztab + (2u * n + 1u); // (behind the table by doubled rank: the dense copy for whole ranks)
-        for (unsigned i = (unsigned)tid; i <= n; i += blockDim.x) lz[i] = gzd[i];
+        if (wa.tab_bytes > 0) for (unsigned i = (unsigned)tid; i <= n; i += blockDim.x) lz[i] = gzd[i];
     }
     __syncthreads(); // the only workgroup barrier of the launch
     WDBG(2);
@@ -1333,6 +1340,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         ws->ra = (unsigned long long)(wa.ra + (long long)gw * wa.npad);
         ws->dbg = (unsigned long long)wa.dbg;
         ws->lz = smem0;
+        ws->tab_lds = wa.tab_bytes > 0 ? 1u : 0u;
         ws->gw = gw;
         ws->stop = wa.stop;
     }
@@ -1414,10 +1422,16 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
 // ------------------------------------------------------------------ host side
 static int g_debug_waves = 0;
 void set_debug_waves(int w) { g_debug_waves = w; }
+static int g_tab_mode = 0; // 0: by the rule below; 1: always in LDS; 2: never (diagnostics, MDT_WAVE_TAB)
+void set_tab_mode(int t) { g_tab_mode = t; }
 
 Geo geometry(long long n, int f32) {
     Geo g;
     g.tab_bytes = (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16);
+    // above 4096 values the table (64 KB at 8000) would leave 8 waves per CU: the series phase then reads its entries from the dense
+    // global copy instead (L2) and the workgroup keeps its 12 waves -- 1000 x 8 x 50 000: 13.6 -> 13.2 ms; below, the LDS table is the
+    // faster one by 0.5 - 2 % (round 5, MDT_WAVE_TAB = 1 / 2 forces either)
+    if (g_tab_mode == 2 || (g_tab_mode == 0 && n > 4096)) g.tab_bytes = 0;
     int wv = (LDS_TOTAL - g.tab_bytes) / PERWAVE;
     if (wv > NTHREADS / 64) wv = NTHREADS / 64;
     if (g_debug_waves > 0 && g_debug_waves < wv) wv = g_debug_waves; // diagnostics (MDT_WAVE_WAVES): fewer waves per workgroup
