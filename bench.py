@@ -352,6 +352,13 @@ def other_configs(pkg, device, steps, warmup):
     return out
 
 
+def wave_rule(D, C, P, split=2):
+    """the host's dispatch rule for the wave-per-parameter kernel (run() in csrc/mdt_hip.hip): slices of 256 ... 8192
+    values in at most 16 split chains of 8 ... 640 draws, from the parameter count at which a wave per parameter pays"""
+    n, niter = D * C, D // split
+    return 256 <= n <= 8192 and 8 <= niter <= 640 and split * C <= 16 and P >= (3 * n if n > 4096 else 700 + (4 * n) // 3)
+
+
 def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
     """the fused bulk+tail request over draws x chains shapes at ~1.6 GB of Float64 each: every boundary between the paths
     (wave-per-parameter kernel up to 8192 values per slice in split chains of at most 640 draws, 256- / 512-thread workgroups per parameter beyond) is visible
@@ -367,7 +374,7 @@ def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
             b_alg = D * C * 8 + 4 * 8
             rows.append({"draws": D, "chains": C, "params": P, "ms": round(ms, 3), "param_series_per_s": round(P / (ms * 1e-3), 1),
                          "hbm_frac": round(P * b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "path": "wave" if D * C <= 8192 and D // 2 <= 640 and 2 * C <= 16 else ("wg256" if D * C <= 12288 and D // 2 <= 1392 else "wg512")})
+                         "path": "wave" if wave_rule(D, C, P) else ("wg256" if D * C <= 12288 and D // 2 <= 1392 else "wg512")})
             del x, x_pcd, outs
             torch.cuda.empty_cache()
     return {"note": "bulk+tail, split_chains 2, maxlag 250, ~1.6 GB of Float64 per shape, 3 timed steps after 1 warm-up; path = which kernel "
