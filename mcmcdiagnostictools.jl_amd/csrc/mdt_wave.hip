@@ -54,10 +54,10 @@ constexpr int NTHREADS = 768;      // at most 12 waves per workgroup (3 per SIMD
 
 // ---- per-wave LDS (bytes from the wave's base)
 constexpr int OFF_SP = 0;                              // double sp[130]: sp[0] = min, sp[1 + i] = splitter i (i < 127), sp[128] = +inf
-constexpr int OFF_IW = OFF_SP + 130 * 8;               // double iw[128]: 1 / width of every class
+constexpr int OFF_IW = OFF_SP + 130 * 8;               // float iw[128]: 1 / width of every class (only the fine bins of a round are cut with it: any monotone cut ranks the same)
 constexpr int OFF_LAGA = OFF_SP;                       // (series phase, over the dead splitters) double lagA[256]
-constexpr int OFF_CCUR = OFF_IW + 128 * 8;             // unsigned ccur[128]: class histogram, then cursors
-constexpr int OFF_RTAB = OFF_CCUR + 128 * 4;           // unsigned short rtab[MAXROUNDS + 2]: first class of every round
+constexpr int OFF_CCUR = OFF_IW + 128 * 4;             // unsigned ccur[64]: class histogram, then cursors, as packed 16-bit pairs (<= 8192 members); after pass B, read as 16-bit entries, the END of every class
+constexpr int OFF_RTAB = OFF_CCUR + 64 * 4;            // unsigned short rtab[MAXROUNDS + 2]: first class of every round
 constexpr int OFF_OST = ((OFF_RTAB + (MAXROUNDS + 2) * 2 + 7) / 8) * 8; // double ostat[8]
 constexpr int OFF_ORK = OFF_OST + 8 * 8;               // unsigned orank[8]: doubled tied rank of every captured order statistic
 constexpr int OFF_LCUR = OFF_ORK + 8 * 4;              // unsigned lcur[16]: fill of every split chain's rank list
@@ -71,7 +71,9 @@ constexpr int OFF_VIEW = ((OFF_PROF + 25 * 8 + 15) / 16) * 16;
 #else
 constexpr int OFF_VIEW = ((OFF_PROF + 15) / 16) * 16;
 #endif
-static_assert(OFF_LAGA + 256 * 8 <= OFF_CCUR, "lag table lives over the splitter tables");
+// (iw as floats and the cursors packed: 768 bytes of the 704 that a twelfth wave per CU needs beside the 32 KB table of a 4000-value slice --
+// 11 -> 12 waves is worth 4.3 %, measured on 724 x 4 where both fit: 10.45 -> 10.0 ms)
+static_assert(OFF_LAGA + 256 * 8 <= OFF_MEAN, "lag table lives over the tables that are dead once the rounds are done (splitters, widths, cursors, round table, order statistics, list fills)");
 // rank view
 constexpr int OFF_VAL = OFF_VIEW;                      // double val[WR]; during passes A / B: uint8 cls[WV_MAXN]
 constexpr int OFF_TAG = OFF_VAL + WR * 8;              // unsigned tag[WR]
@@ -310,7 +312,7 @@ constexpr int UB = 8; // rows per batch of the streaming passes
 WV_PHASE void ph_classify(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* sp = (WV_LA double*)(wb + OFF_SP);
-    WV_LA double* iw = (WV_LA double*)(wb + OFF_IW);
+    WV_LA float* iw = (WV_LA float*)(wb + OFF_IW);
     WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
     WV_LA unsigned short* rtab = (WV_LA unsigned short*)(wb + OFF_RTAB);
     WV_LA unsigned char* clsb = (WV_LA unsigned char*)(wb + OFF_VAL);
@@ -349,17 +351,16 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
         }
         sp[1 + lane] = a;
         sp[65 + lane] = (lane == 63) ? inf : b; // 127 splitters; the sentinel ends the search
-        ccur[lane] = 0u;
-        ccur[64 + lane] = 0u;
+        ccur[lane] = 0u; // (two classes per word)
         lds_fence();
 #pragma unroll
         for (int q = 0; q < 2; ++q) { // inverse widths of the inner classes c = 1 .. 126: [sp[c], sp[c + 1])
             const int c = lane + 64 * q;
             if (c >= 1 && c <= 126) {
                 const double wd = sp[c + 1] - sp[c];
-                double v = (wd > 0.0 && wd < inf) ? 1.0 / wd : 0.0;
-                if (!(v < inf)) v = 0.0;
-                iw[c] = v;
+                const double v = (wd > 0.0 && wd < inf) ? 1.0 / wd : 0.0;
+                const float vf = (float)v;
+                iw[c] = (vf < __builtin_inff()) ? vf : 0.0f; // (a class too narrow for a float's range: one fine bin)
             }
         }
     }
@@ -401,7 +402,7 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
                     bad |= (v[u] - v[u] == 0.0) ? 0u : 1u;
                     xmin = v[u] < xmin ? v[u] : xmin;
                     xmax = v[u] > xmax ? v[u] : xmax;
-                    lds_add(&ccur[pos[u]], 1u);
+                    lds_add(&ccur[pos[u] >> 1], 1u << ((pos[u] & 1u) << 4));
                     clsb[ra_.eb + ra_.d] = (unsigned char)pos[u];
                 }
             }
@@ -414,7 +415,7 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
         xmin = wave_min_d(xmin);
         xmax = wave_max_d(xmax);
         lds_fence();
-        const unsigned h0 = ccur[2 * lane], h1 = ccur[2 * lane + 1];
+        const unsigned hw = ccur[lane], h0 = hw & 0xFFFFu, h1 = hw >> 16;
         const unsigned tot = h0 + h1, incl = wave_incl_scan_u32(tot);
         const unsigned b0 = incl - tot, b1 = b0 + h0;
         const unsigned cmax = rflu(wave_max_u32(h0 > h1 ? h0 : h1));
@@ -430,8 +431,7 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
             if (nrounds > (unsigned)MAXROUNDS) fallback = true;
             else {
                 lds_fence();
-                ccur[2 * lane] = b0;
-                ccur[2 * lane + 1] = b1;
+                ccur[lane] = b0 | (b1 << 16); // (b1 <= n <= 8192: no carry between the halves while pass B counts them up)
                 if (f0) rtab[kx] = (unsigned short)(2 * lane);
                 if (f1) rtab[kx + f0] = (unsigned short)(2 * lane + 1);
                 if (lane == 0) {
@@ -439,8 +439,9 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
                     sp[0] = xmin;
                     const double w0 = sp[1] - xmin, w1 = xmax - sp[127];
                     const double v0 = (w0 > 0.0 && w0 < inf) ? 1.0 / w0 : 0.0, v1 = (w1 > 0.0 && w1 < inf) ? 1.0 / w1 : 0.0;
-                    iw[0] = (v0 < inf) ? v0 : 0.0;
-                    iw[127] = (v1 < inf) ? v1 : 0.0;
+                    const float f0 = (float)v0, f1 = (float)v1;
+                    iw[0] = (f0 < __builtin_inff()) ? f0 : 0.0f;
+                    iw[127] = (f1 < __builtin_inff()) ? f1 : 0.0f;
                 }
             }
         }
@@ -487,7 +488,8 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
             const unsigned r = r0 + (unsigned)u;
             const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
             if (r < NRW && ra_.d < D) {
-                const unsigned pos = lds_add(&ccur[cl[u]], 1u);
+                const unsigned shc = (cl[u] & 1u) << 4;
+                const unsigned pos = (lds_add(&ccur[cl[u] >> 1], 1u << shc) >> shc) & 0xFFFFu;
                 unsigned k = 0u; // (s - 1 steps, usually one: kept from the loop vectoriser, which interleaved it by two behind a remainder loop)
 #pragma clang loop vectorize(disable) interleave(disable)
                 for (unsigned kk = 1u; kk < s; ++kk) k += (ra_.d >= row0(kk)) ? 1u : 0u;
@@ -505,8 +507,8 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
 WV_PHASE void ph_rounds(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* sp = (WV_LA double*)(wb + OFF_SP);
-    WV_LA double* iw = (WV_LA double*)(wb + OFF_IW);
-    WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
+    WV_LA float* iw = (WV_LA float*)(wb + OFF_IW);
+    const WV_LA unsigned short* cend_cls = (const WV_LA unsigned short*)(wb + OFF_CCUR); // (pass B has counted every class's cursor up to its end)
     WV_LA unsigned short* rtab = (WV_LA unsigned short*)(wb + OFF_RTAB);
     WV_LA double* ostat = (WV_LA double*)(wb + OFF_OST);
     WV_LA unsigned* orank = (WV_LA unsigned*)(wb + OFF_ORK);
@@ -544,8 +546,8 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     unsigned tg[RROWS];
     auto round_span = [&](unsigned r, unsigned& cA, unsigned& cB, unsigned& g0, unsigned& g1) {
         cA = rflu((unsigned)rtab[r]); cB = rflu((unsigned)rtab[r + 1]);
-        g0 = cA ? rflu(ccur[cA - 1u]) : 0u;
-        g1 = rflu(ccur[cB - 1u]);
+        g0 = cA ? rflu((unsigned)cend_cls[cA - 1u]) : 0u;
+        g1 = rflu((unsigned)cend_cls[cB - 1u]);
     };
     auto issue = [&](unsigned r) {
         unsigned cA, cB, g0, g1;
@@ -574,7 +576,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
         {
             double lo[RROWS], wd[RROWS];
 #pragma unroll
-            for (int i = 0; i < RROWS; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = iw[cls]; }
+            for (int i = 0; i < RROWS; ++i) { const unsigned cls = tg[i] >> 24; lo[i] = sp[cls]; wd[i] = (double)iw[cls]; }
 #pragma unroll
             for (int i = 0; i < RROWS; ++i) {
                 // piecewise-linear fine bin inside the class; sub-bin 0 = equal to the class's lower bound (a constant bin)
