@@ -4,6 +4,7 @@
 # mdt_small<float>, mdt_tiny<double>), calibrated memory-side traffic and the SQ instruction counters of the five measured
 # workloads (separate passes per counter group), phase tables.
 # usage (inside gpurun): bash tools/collect_profiles.sh <tag>      then, back home: python tools/summarize_profiles.py <tag>
+# (gpurun merges the box's gpurun_out/<tag> into the local one: `rm -rf gpurun_out/<tag>` first, or files of an earlier collection stay beside the new ones)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r05}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err

@@ -70,7 +70,14 @@ for name in ("phase_cfg2", "phase_cfg3", "phase_cfg5_rank", "cfg5_split", "wave_
 
 def rows(pattern, pats):
     out = []
+    # gpurun MERGES a collection into the local directory: passes of earlier collections stay beside the new ones (other process ids in
+    # the file names) -- only the newest file of every pass directory is this collection's
+    newest = {}
     for f in glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")):
+        d = os.path.dirname(f)
+        if d not in newest or os.path.getmtime(f) > os.path.getmtime(newest[d]):
+            newest[d] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             if any(p in r["Kernel_Name"] for p in pats):
                 out.append(r)
