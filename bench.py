@@ -354,14 +354,14 @@ def other_configs(pkg, device, steps, warmup):
 
 def wave_rule(D, C, P, split=2):
     """the host's dispatch rule for the wave-per-parameter kernel (run() in csrc/mdt_hip.hip): slices of 256 ... 8192
-    values in at most 16 split chains of 8 ... 640 draws, from the parameter count at which a wave per parameter pays"""
+    values in at most 16 split chains of 8 ... 1024 draws, from the parameter count at which a wave per parameter pays"""
     n, niter = D * C, D // split
-    return 256 <= n <= 8192 and 8 <= niter <= 640 and split * C <= 16 and P >= (3 * n if n > 4096 else 700 + (4 * n) // 3)
+    return 256 <= n <= 8192 and 8 <= niter <= 1024 and split * C <= 16 and P >= (3 * n if (n > 4096 or niter > 640) else 700 + (4 * n) // 3)
 
 
 def shape_sweep(pkg, device, target_bytes=1.6e9, steps=3):
     """the fused bulk+tail request over draws x chains shapes at ~1.6 GB of Float64 each: every boundary between the paths
-    (wave-per-parameter kernel up to 8192 values per slice in split chains of at most 640 draws, 256- / 512-thread workgroups per parameter beyond) is visible
+    (wave-per-parameter kernel up to 8192 values per slice in split chains of at most 1024 draws, 256- / 512-thread workgroups per parameter beyond) is visible
     in the driver's record"""
     rows = []
     for D in (250, 500, 1_000, 2_000, 5_000, 10_000):

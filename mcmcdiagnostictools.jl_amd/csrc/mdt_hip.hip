@@ -624,7 +624,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // table leaves room for 8 waves per CU and the crossover moves out (1000 x 8: 16 000 parameters 5.2 against 4.9 ms, 50 000: 13.5
     // against 14.6).  Hence the parameter count in the rule.
     const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
-    const bool wave_pays = P >= (n > 4096 ? 3 * n : 700 + (4 * n) / 3);
+    // (split chains of more than 640 draws take the longer per-wave LDS block -- 10 waves beside a 4000-value table --: 2000 x 2 ties at
+    // 8000 parameters and wins 15 % at 16 000)
+    const bool wave_pays = P >= ((n > 4096 || niter > (long long)mdtw::WV_NITER_SHORT) ? 3 * n : 700 + (4 * n) / 3);
     const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
                       (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) &&
                       n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER &&
@@ -677,7 +679,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (wave) {
         mdtw::set_debug_waves(hook("MDT_WAVE_WAVES") ? atoi(hook("MDT_WAVE_WAVES")) : 0);
         mdtw::set_tab_mode(hook("MDT_WAVE_TAB") ? atoi(hook("MDT_WAVE_TAB")) : 0);
-        wgeo = mdtw::geometry(n, f32 ? 1 : 0);
+        wgeo = mdtw::geometry(n, niter, f32 ? 1 : 0);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         wave_wgs = (int)std::min<long long>(ncu, (P + wgeo.waves - 1) / wgeo.waves);
         // (the scratch is sized for a full grid: the same buffer serves every request of the shape)
@@ -1154,7 +1156,8 @@ int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
     if (int rc = ensure_scratch(ctx, n, wgs)) return rc;
     if (int rc = ensure_ztab(ctx, n, a->dtype == MDT_F32 ? 1 : 0, st)) return rc;
     if (n >= 256 && n <= (long long)mdtw::WV_MAXN) {
-        const mdtw::Geo g = mdtw::geometry(n, a->dtype == MDT_F32 ? 1 : 0);
+        // (the block of short split chains holds the most waves: the scratch is sized for those)
+        const mdtw::Geo g = mdtw::geometry(n, 1, a->dtype == MDT_F32 ? 1 : 0);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         const size_t need = mdtw::scratch_bytes(g, (long long)ncu * g.waves);
         if (need > ctx->wv_cap) {

@@ -10,17 +10,19 @@ namespace mdtw {
 // limits of the path (everything else is served by the workgroup-per-parameter kernels of mdt_device.hpp)
 constexpr int WV_MAXN = 8192;     // draws * chains
 constexpr int WV_MAXM = 16;       // chains * split_chains
-constexpr int WV_NITER = 640;     // draws / split_chains
+constexpr int WV_NITER = 1024;    // draws / split_chains (above WV_NITER_SHORT the per-wave LDS block is the longer one: fewer waves per CU)
+constexpr int WV_NITER_SHORT = 640;
 constexpr int WV_MAXLAG = 255;    // effective maxlag
 
 // per-launch geometry, fixed by the slice size and the element type
 struct Geo {
+    int perwave;    // bytes of LDS per wave: the block of short split chains or the longer one
     int waves;          // waves per workgroup (one workgroup per CU)
     int tab_bytes;      // LDS bytes of the normal-score table shared by the workgroup
     int lds_bytes;      // dynamic LDS of the launch
     long long npad;     // elements of per-wave scratch
 };
-Geo geometry(long long n, int f32);
+Geo geometry(long long n, long long niter, int f32);
 // bytes of per-wave scratch in global memory for `waves_total` waves
 size_t scratch_bytes(const Geo& g, long long waves_total);
 void set_debug_buf(unsigned* host_pinned); // diagnostics: progress word per wave

@@ -103,8 +103,9 @@ constexpr int OFF_SB2 = OFF_IMEAN + 2 * WV_MAXM * 8;   // uint64 sb2[2 m nwU] (t
 constexpr int SB2_WORDS = 2 * (WV_MAXN / 64 + 6 * WV_MAXM);  // 2 m nwU with nwU <= niter / 64 + 6 and m niter <= WV_MAXN
 constexpr int END_IND = OFF_SB2 + SB2_WORDS * 8;
 constexpr int cmax2(int a, int b) { return a > b ? a : b; }
-constexpr int PERWAVE = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER, END_IND)) + 15) / 16) * 16;
-constexpr int VIEW_BYTES = PERWAVE - OFF_VIEW;
+constexpr int PERWAVE = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER, END_IND)) + 15) / 16) * 16;   // split chains of up to WV_NITER draws
+constexpr int END_SER_SHORT = OFF_STG + (64 * ((WV_NITER_SHORT + 63) / 64) + 272) * 8;
+constexpr int PERWAVE_SHORT = ((cmax2(cmax2(END_RANK, END_FOLD), cmax2(END_SER_SHORT, END_IND)) + 15) / 16) * 16; // ... of up to WV_NITER_SHORT: what a sampler's 1000 x 4 needs, 12 waves beside its table
 constexpr int LDS_TOTAL = 160 * 1024;
 
 // one member of the slice in the per-wave scratch, 12 bytes (one store / one load per member): its value and a tag -- in the
@@ -133,6 +134,7 @@ struct WvArgs {
     int* fb_count;
     long long npad;
     int tab_bytes;
+    int perwave;           // bytes of LDS per wave (PERWAVE_SHORT or PERWAVE)
     unsigned* dbg;         // diagnostics (MDT_WAVE_DBG = address of a host-pinned array): progress word of every wave, or null
     int stop;              // diagnostics (MDT_WAVE_STOP behind the test-hooks gate): the parameter ends after phase `stop` with NaN outputs; 0 = never
 };
@@ -154,6 +156,7 @@ struct WS {
     int fallback, zq_ok, bits_done, stop;
     unsigned lz, gw;                  // LDS address of the score table; global wave index
     unsigned tab_lds;                 // the score table of whole ranks sits in LDS (else: read from the global copy)
+    unsigned view_bytes;              // bytes of the wave's block behind OFF_VIEW
 };
 static_assert(sizeof(WS) <= WS_BYTES, "wave state block");
 #define WV_LA __attribute__((address_space(3)))
@@ -955,7 +958,7 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
     // indicator words behind the stage, when both fit the view
     const int nwS = (int)nblk, nwU = nwS + (int)(maxlag >> 6) + 2;
     const unsigned stg_doubles = 64u * nblk + 272u;
-    const bool bits = kp.need_et && kp.ess_ok && rfl(ws->zq_ok) != 0 && (int)(stg_doubles * 8u) + 2 * m * nwU * 8 <= VIEW_BYTES;
+    const bool bits = kp.need_et && kp.ess_ok && rfl(ws->zq_ok) != 0 && (int)(stg_doubles * 8u) + 2 * m * nwU * 8 <= (int)rflu(ws->view_bytes);
     WV_LA unsigned long long* sb2 = (WV_LA unsigned long long*)(stage + stg_doubles);
     const unsigned r2q0 = rflu(ws->r2q[0]), r2q1 = rflu(ws->r2q[1]);
     if (bits) { for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull; }
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
     __syncthreads(); // the only workgroup barrier of the launch
     WDBG(2);
     const unsigned smem0 = (unsigned)(unsigned long long)(WV_LA unsigned char*)smem;
-    const unsigned wbase = rflu(smem0 + (unsigned)wa.tab_bytes + (unsigned)w * (unsigned)PERWAVE);
+    const unsigned wbase = rflu(smem0 + (unsigned)wa.tab_bytes + (unsigned)w * (unsigned)wa.perwave);
     WV_LA unsigned char* wb = (WV_LA unsigned char*)(unsigned long long)wbase;
     WV_LA WS* ws = (WV_LA WS*)(wb + OFF_WS);
     if (lane == 0) {
@@ -1343,6 +1346,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         ws->dbg = (unsigned long long)wa.dbg;
         ws->lz = smem0;
         ws->tab_lds = wa.tab_bytes > 0 ? 1u : 0u;
+        ws->view_bytes = (unsigned)(wa.perwave - OFF_VIEW);
         ws->gw = gw;
         ws->stop = wa.stop;
     }
@@ -1386,12 +1390,14 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
                         if (kp.need_eb || kp.need_rb) {
                             if (nblk <= 4u) ph_series<T, 4>(wbase);
                             else if (nblk <= 8u) ph_series<T, 8>(wbase);
+                            else if (nblk <= (unsigned)((WV_NITER_SHORT + 63) / 64)) ph_series<T, (WV_NITER_SHORT + 63) / 64>(wbase);
                             else ph_series<T, (WV_NITER + 63) / 64>(wbase);
                         }
                         WDBG(60);
                         if (kp.need_et && kp.ess_ok && stop != 5) {
                             if (nblk <= 4u) ph_indicators<T, 4>(wbase);
                             else if (nblk <= 8u) ph_indicators<T, 8>(wbase);
+                            else if (nblk <= (unsigned)((WV_NITER_SHORT + 63) / 64)) ph_indicators<T, (WV_NITER_SHORT + 63) / 64>(wbase);
                             else ph_indicators<T, (WV_NITER + 63) / 64>(wbase);
                         }
                     }
@@ -1427,19 +1433,20 @@ void set_debug_waves(int w) { g_debug_waves = w; }
 static int g_tab_mode = 0; // 0: by the rule below; 1: always in LDS; 2: never (diagnostics, MDT_WAVE_TAB)
 void set_tab_mode(int t) { g_tab_mode = t; }
 
-Geo geometry(long long n, int f32) {
+Geo geometry(long long n, long long niter, int f32) {
     Geo g;
     g.tab_bytes = (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16);
     // above 4096 values the table (64 KB at 8000) would leave 8 waves per CU: the series phase then reads its entries from the dense
     // global copy instead (L2) and the workgroup keeps its 12 waves -- 1000 x 8 x 50 000: 13.6 -> 13.2 ms; below, the LDS table is the
     // faster one by 0.5 - 2 % (round 5, MDT_WAVE_TAB = 1 / 2 forces either)
     if (g_tab_mode == 2 || (g_tab_mode == 0 && n > 4096)) g.tab_bytes = 0;
-    int wv = (LDS_TOTAL - g.tab_bytes) / PERWAVE;
+    g.perwave = niter <= WV_NITER_SHORT ? PERWAVE_SHORT : PERWAVE;
+    int wv = (LDS_TOTAL - g.tab_bytes) / g.perwave;
     if (wv > NTHREADS / 64) wv = NTHREADS / 64;
     if (g_debug_waves > 0 && g_debug_waves < wv) wv = g_debug_waves; // diagnostics (MDT_WAVE_WAVES): fewer waves per workgroup
     if (wv < 1) wv = 1;
     g.waves = wv;
-    g.lds_bytes = g.tab_bytes + wv * PERWAVE;
+    g.lds_bytes = g.tab_bytes + wv * g.perwave;
     g.npad = ((n + 63) / 64) * 64;
     return g;
 }
@@ -1468,6 +1475,7 @@ void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgr
     wa.fb_count = fb_count;
     wa.npad = g.npad;
     wa.tab_bytes = g.tab_bytes;
+    wa.perwave = g.perwave;
     wa.stop = g_debug_stop;
     wa.dbg = g_debug_buf;
     if (f32) hipLaunchKernelGGL(wave_kernel<float>, dim3((unsigned)workgroups), dim3((unsigned)(64 * g.waves)), (size_t)g.lds_bytes, st, kp_slot, wa);

@@ -1562,7 +1562,7 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
     for what, xs in shapes:
         for s in (2, 1, 3):
             D, C = xs.shape[:2]
-            if C * s > 16 or D // s > 640 or D // s < 8 or D * C < 256 or D * C > 8192:
+            if C * s > 16 or D // s > 1024 or D // s < 8 or D * C < 256 or D * C > 8192:
                 continue
             xd = dev(xs)
             monkeypatch.setenv("MDT_WAVE", "2")

@@ -3,7 +3,7 @@
 kinds, autocov methods, data flavours and geometries against the C oracle.  python tools/fuzz_soak.py [seconds] [seed] [long|many|order|wave]
 (long: chains of 50 000 - 131 072 draws, maxlag up to 1000; many: 100 - 1500 chains, more split chains than the LDS moment tables hold;
 order: 600 - 4000 short parameters per request, each request issued twice -- the second launch hands its tickets out by
-the costs the first one measured; wave: slices of 256 ... 8192 values in up to 16 split chains, 1 - 300 parameters per request, the
+the costs the first one measured; wave: slices of 256 ... 8192 values in up to 16 split chains of up to 1024 draws, 1 - 300 parameters per request, the
 geometry never forced: the wave-per-parameter kernel of round 5 and, for what it hands back, the general kernel behind it.
 Every mode forces the tile-major partition (MDT_PA=2) on every other request.)"""
 import os, sys, time, warnings
@@ -79,7 +79,7 @@ while time.time() - t0 < budget:
     if WAVE:
         os.environ["MDT_WAVE"] = "2"  # (the default takes the wave kernel only from a few thousand parameters on)
         C = int(rng.integers(1, 9))
-        D = int(rng.integers(max(8 * s, (256 + C - 1) // C), min(640 * s, 8192 // C) + 1))
+        D = int(rng.integers(max(8 * s, (256 + C - 1) // C), min(1024 * s, 8192 // C) + 1))
         P = int(rng.choice([1, 3, 17, 300]))
     if it % 2:
         os.environ["MDT_PA"] = "2"
