@@ -614,7 +614,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool tiny = force_cfg == 0 ? (tiny_fits && !onechunk) : (force_cfg == 3 && tiny_fits);
     const bool small = tiny ? false : (force_cfg == 1 ? false : small_fits); // 80 KiB tables, two workgroups per CU
     // Short slices, one parameter per WAVE (mdt_wave.hip): rank-normalised requests (kinds bulk / tail / rank and the fused one) on
-    // slices of 256 ... 8192 values in at most 16 split chains of 8 ... 640 draws, effective maxlag <= 255, AutocovMethod or
+    // slices of 256 ... 8192 values in at most 16 split chains of 8 ... 1024 draws, effective maxlag <= 255, AutocovMethod or
     // FFTAutocovMethod (evaluated from lag products, as everywhere).  Parameters it cannot serve (a NaN, an infinity, a point mass
     // larger than a round, many ties among the folded values) come back in a list and the general kernel, queued behind it, works
     // that list off.  MDT_WAVE=0: never, 2: wherever it can run (tests, A/B timing; needs MDT_TEST_HOOKS=1 like every switch)
