@@ -5,9 +5,11 @@
 // few dependent LDS or L2 round trips: 2.6 % of the HBM roof at 1000 x 4, 1.5 % at 500 x 4.  Here a
 // wave64 owns a parameter from its ticket to its four outputs and synchronises with nobody: waves of a CU drift apart, and
 // whenever one waits for memory or the LDS the others issue.  What makes that possible is that nothing of the size of the
-// slice lives in LDS: a wave holds ~12 KB (one ROUND of the ranking, one fold tile, one split chain), the slice itself
+// slice lives in LDS: a wave holds 10.9 KB (one ROUND of the ranking, one fold tile, one split chain; 13.1 KB for split chains of
+// more than 640 draws), the slice itself
 // passes through a per-wave scratch in global memory that stays in the L2 / Infinity Cache, and the normal-score table of
-// the shape (src/utils.jl:182, 189-193) is shared by the waves of a workgroup, read-only, in LDS.
+// the shape (src/utils.jl:182, 189-193) is shared by the waves of a workgroup, read-only, in LDS (up to 4096 values; above, the series
+// phase reads it from its global copy and the workgroup keeps its twelve waves).
 //
 // Per parameter (reference: src/ess_rhat.jl:517-594, src/utils.jl:148-193):
 //   sample     128 values spread over the slice, sorted by the wave (bitonic, shuffles): 127 splitters, 128 classes
@@ -18,11 +20,11 @@
 //              (sub-bin 0 = equal to the class's lower splitter: point masses are constant bins), LDS histogram + prefix,
 //              placement, all-pairs count inside the bin (~1 member): pooled tied rank (StatsBase.tiedrank), order statistics
 //              (median, type-7 quantile neighbours), the sorted copy (in place, over the round's piece of the scratch) and the
-//              doubled rank of every member at its TIME position (2-byte scatter)
+//              doubled rank of every member appended to the rank list of its split chain (draw | rank: semi-coalesced stores)
 //   fold       rhat(kind = tail): |x - median| of the sorted copy is two monotone runs mirrored at the median; their tied
-//              ranks are those of a two-way merge (merge path per lane inside a 256-output tile staged in LDS); scores by
+//              ranks are those of a two-way merge (merge path per lane inside a 512-output tile staged in LDS); scores by
 //              merged position (coalesced), exact fixed-point moments per split chain by LDS atomics
-//   series     per split chain: ranks -> scores (shared LDS table) -> time-order stage in LDS, exact fixed-point moments
+//   series     per split chain: rank list -> time order (LDS) -> scores (shared table) -> stage in LDS, exact fixed-point moments
 //              (the same integers and expressions as every other path: R-hat is the same BITS), centred, lag products as
 //              blocked Hankel tiles on v_mfma_f64_16x16x4_f64 accumulated over the chains; Geyer's scan between lag blocks
 //   indicators tail ESS: ballots of x <= q per split chain, popcount autocovariance, exact integer centring, two scans
@@ -932,7 +934,7 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
 // the same bits); centred; lag products (src/ess_rhat.jl:170-178) as blocked Hankel tiles on v_mfma_f64_16x16x4_f64,
 // accumulated over the chains; Geyer's initial monotone sequence (:555-594) between blocks of 32 lags.  While a chain is
 // staged its tail-ESS indicator words are taken from the ranks (x <= q <=> doubled rank <= r2q).
-// (NB: rows of 64 draws the code is unrolled for -- 4, 8 or 10: the kernel picks the smallest that holds a split chain)
+// (NB: rows of 64 draws the code is unrolled for -- 4, 8, 10 or 16: the kernel picks the smallest that holds a split chain; 16 rows need the longer per-wave block)
 template <typename T, int NB> __device__ __attribute__((noinline)) void ph_series(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* lagA = (WV_LA double*)(wb + OFF_LAGA);
