@@ -113,9 +113,14 @@ const char* mdt_last_error(const mdt_ctx* ctx);
  * Optional: everything a request of this shape would otherwise allocate and build inside its FIRST call -- the per-workgroup
  * and per-wave scratch, the normal-score table of (draws * chains, dtype) (src/utils.jl:182, 189-193: built once per shape),
  * the ticket tables of `params` parameters -- so that the first mdt_ess_rhat / mdt_bulk_tail / ... on the context costs what
- * every later one costs.  A diagnostic is typically called once per array: call this when the sampler's shape is known
- * (args: draws, chains, params, dtype, stream; the rest is ignored).  The reference has no counterpart: its caches are the
- * per-call temporaries of src/ess_rhat.jl:511 and src/utils.jl:170-171.  Returns MDT_OK, MDT_EARG, MDT_ENOMEM, MDT_ERUNTIME.
+ * every later one costs.  A diagnostic is typically called once per array: call this when the sampler's shape is known.
+ * Read from args: draws, chains, params, dtype, stream; split_chains (0: the keyword's default 2 -- it decides which kernel family
+ * the shape is handed to and therefore which scratch is needed); chain_stride / param_stride (a strided layout -- MCMCChains
+ * storage -- also gets its per-workgroup gather buffer); location (MDT_HOST: the whole-array staging buffers of a host request
+ * below 128 MB; larger host arrays travel in blocks whose buffers the first request allocates beside its PCIe copy).  The rest is
+ * ignored.  Not covered: the side tables of mdt_rhat_nested / mdt_mcse_quantile (a few KB, allocated by their first request).
+ * The reference has no counterpart: its caches are the per-call temporaries of src/ess_rhat.jl:511 and src/utils.jl:170-171.
+ * Returns MDT_OK, MDT_EARG, MDT_EDIM, MDT_EUNSUPPORTED (draws * chains beyond the ranking's range), MDT_ENOMEM, MDT_ERUNTIME.
  */
 int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* args);
 

@@ -120,14 +120,18 @@ function status(; devices=nothing, clear::Bool=true)
     return f[]
 end
 
-"""    reserve(draws, chains, params; T=Float64, devices=nothing)
+"""    reserve(draws, chains, params; T=Float64, devices=nothing, split_chains=2, host=false)
 
 Allocate and build, before the first request, what a `(draws, chains, params)` array of eltype `T` needs on the context
 (mdt_ctx_reserve): scratch, the normal-score table of the shape, ticket tables.  Optional -- a diagnostic is usually
-called once per array, and without this its one call also pays for the allocations."""
-function reserve(draws::Integer, chains::Integer, params::Integer; T::Type{<:Union{Float64,Float32}}=Float64, devices=nothing)
+called once per array, and without this its one call also pays for the allocations.  The context warmed is the one a
+request with the same `devices` resolves to (`_ctx_for`: this shim keeps one context per device set, whatever the
+stream); `host = true` announces an `Array` in host memory (its staging buffers are reserved too), `split_chains` the
+keyword the request will carry (it decides which kernel family the shape is handed to)."""
+function reserve(draws::Integer, chains::Integer, params::Integer; T::Type{<:Union{Float64,Float32}}=Float64, devices=nothing,
+                 split_chains::Integer=2, host::Bool=false)
     h = _ctx_for(devices)
-    a = MdtArgs(draws, chains, params, T === Float32 ? 1 : 0, 1, 0, 0, 0, 2, 0, 1, 250, 0.1, C_NULL)
+    a = MdtArgs(draws, chains, params, T === Float32 ? 1 : 0, host ? 0 : 1, 0, 0, 0, split_chains, 0, 1, 250, 0.1, C_NULL)
     _locked() do
         _check(h, ccall((:mdt_ctx_reserve, libmdt), Cint, (Ptr{Cvoid}, Ref{MdtArgs}), h, a))
     end

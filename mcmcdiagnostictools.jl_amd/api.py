@@ -178,6 +178,44 @@ def _prepare(samples, allow_strided=False):
     return pr
 
 
+def _describe(samples):
+    """shape, eltype, location and layout of the request `samples` would make -- what _prepare finds, without copying
+    anything (reserve(like=...))"""
+    ma = sys.modules.get("numpy.ma")
+    if ma is not None and isinstance(samples, ma.MaskedArray):
+        samples = samples.data
+    pr = _Prepared()
+    is_torch = torch is not None and isinstance(samples, torch.Tensor)
+    if not is_torch:
+        samples = np.asarray(samples)
+    if samples.ndim < 1:
+        raise ArgumentError("`samples` must have at least 1 dimension")
+    shape = tuple(samples.shape)
+    D = shape[0]
+    C = shape[1] if len(shape) > 1 else 1
+    P = 1
+    for d in shape[2:]:
+        P *= d
+    pr.D, pr.C, pr.P = D, C, P
+    pr.cs = pr.ps = 0
+    pr.shards = None
+    if is_torch and samples.is_cuda:
+        pr.dev, pr.device_index, pr.buf = True, samples.device.index, samples
+        pr.f32 = samples.dtype == torch.float32 or (samples.dtype != torch.float64 and samples.dtype.is_floating_point)
+        if D * C * P > 0:
+            st = samples.reshape(D, C, P).stride() if samples.is_contiguous() or samples.dim() == 3 else None
+            if st is not None:
+                dense = (st[0] == 1 or D == 1) and (st[1] == D or C == 1) and (st[2] == D * C or P == 1)
+                if not dense and (st[0] == 1 or D == 1) and (st[1] >= D or C == 1) and (st[2] >= 1 or P == 1):
+                    pr.cs = int(st[1]) if C > 1 else D
+                    pr.ps = int(st[2]) if P > 1 else max(1, (C - 1) * pr.cs + D)
+    else:
+        pr.dev, pr.device_index, pr.buf = False, 0, None
+        dtn = samples.dtype
+        pr.f32 = (dtn == torch.float32) if is_torch else (dtn == np.float32)
+    return pr
+
+
 def _prepare_shards(shards):
     """PRE-SHARDED input of a multi-GPU context (mdt_args.x_shards): a list of CUDA tensors, block i of the params axis on
     GPU devices[i], each of shape (draws, chains, p_i) with p_i = shard_bounds(sum p_i, i, len(shards)) -- no input
@@ -269,23 +307,40 @@ def status(device=None, *, devices=None, clear=True):
 FLAG_RANK_OVERFLOW, FLAG_NAN_QUANTILE, FLAG_FDIST = _lib.FLAG_RANK_OVERFLOW, _lib.FLAG_NAN_QUANTILE, _lib.FLAG_FDIST
 
 
-def reserve(draws, chains, params, *, dtype=np.float64, device=None, devices=None):
-    """Allocate and build, before the first request, what a (draws, chains, params) array of `dtype` needs on the context
-    of (device, current stream) -- or of the multi-GPU context over `devices` -- : scratch, the normal-score table of
-    the shape, ticket tables (mdt_ctx_reserve).  Optional: a diagnostic is usually called once per array, and without
-    this its one call also pays for the allocations.  No counterpart in the reference (its caches are per-call
-    temporaries, src/ess_rhat.jl:511)."""
-    dt = np.dtype(dtype)
+def reserve(draws, chains, params, *, dtype=np.float64, device=None, devices=None, like=None, split_chains=2):
+    """Allocate and build, before the first request, what a (draws, chains, params) array of `dtype` needs: scratch, the
+    normal-score table of the shape, ticket tables (mdt_ctx_reserve).  Optional: a diagnostic is usually called once per
+    array, and without this its one call also pays for the allocations.  No counterpart in the reference (its caches are
+    per-call temporaries, src/ess_rhat.jl:511).
+
+    Which context is warmed -- the same rule as a request (`_ctx_key`): with `like=` (the array the request will be made on,
+    or any array of its kind) exactly the context that request resolves to, shape / dtype / layout taken from it; a host
+    (numpy) array lives on context (device 0, stream 0) and also gets its staging buffers.  Without `like` a DEVICE request
+    is assumed: the context of (`device` or the current device, that device's current stream) -- reserve under the stream
+    the request will run on --, or the multi-GPU context over `devices`."""
+    a_like = None
+    if like is not None:
+        pr = _describe(like)
+        draws, chains, params = pr.D, pr.C, pr.P
+        dt = np.dtype(np.float32 if pr.f32 else np.float64)
+        key = _ctx_key(pr, devices)
+        a_like = _args(pr, 0, 0, 0, split_chains, 250, False, 0.1)
+    else:
+        dt = np.dtype(dtype)
     if dt not in (np.dtype(np.float64), np.dtype(np.float32)):
         raise ArgumentError("dtype must be float64 or float32")
-    if devices is not None:
-        key, stream = (tuple(int(d) for d in devices), None), None
+    if a_like is not None:
+        a = a_like
+        a.x_shards = None
     else:
-        dev = torch.cuda.current_device() if device is None else int(device)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        key = (dev, stream)
-    a = _lib.MdtArgs(int(draws), int(chains), int(params), _lib.MDT_F32 if dt == np.dtype(np.float32) else _lib.MDT_F64,
-                     _lib.MDT_DEVICE, 0, 0, 0, 2, 0, 1, 250, 0.1, stream, 0, 0)
+        if devices is not None:
+            key, stream = (tuple(int(d) for d in devices), None), None
+        else:
+            dev = torch.cuda.current_device() if device is None else int(device)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            key = (dev, stream)
+        a = _lib.MdtArgs(int(draws), int(chains), int(params), _lib.MDT_F32 if dt == np.dtype(np.float32) else _lib.MDT_F64,
+                         _lib.MDT_DEVICE, 0, 0, 0, int(split_chains), 0, 1, 250, 0.1, stream, 0, 0)
     _call(key, _lib.load().mdt_ctx_reserve, ctypes.byref(a))
 
 

@@ -366,14 +366,11 @@ __global__ void kp_setup_kernel(KP* slot, KP v, int* status, int keep_status) {
         // (keep_status bit 1: the launch works off the list the wave-per-parameter kernel in front of it left: its count stays)
         if (!(keep_status & 1)) { status[2] |= status[0]; status[0] = 0; }
         if (!(keep_status & 2)) status[3] = 0;
+        // keep_status bit 2: the parameters the wave-per-parameter kernel left behind (status[3] of them, listed in the `order` table
+        // of this slot) become the tickets of the general kernel queued behind it -- a count only the device knows
+        if (keep_status & 4) slot->P = status[3];
         status[1] = 0;
     }
-}
-
-// The parameters the wave-per-parameter kernel left behind (status[3] of them, listed in the `order` table of this slot)
-// become the tickets of the general kernel queued behind it: its parameter count is only known on the device.
-__global__ void fb_patch_kernel(KP* slot, const int* status) {
-    if (threadIdx.x == 0) slot->P = status[3];
 }
 
 // the same bookkeeping for the entry points that do not go through mdt_kernel (gelmandiag)
@@ -440,6 +437,29 @@ int fail(mdt_ctx* ctx, int code, const std::string& msg) {
     } while (0)
 
 size_t tsize(int dtype) { return dtype == MDT_F32 ? 4 : 8; }
+
+// per-workgroup dense copy of a parameter whose chains are not contiguous in x (MCMCChains storage): grown lazily
+int ensure_xcbuf(mdt_ctx* ctx, long long wgs) {
+    const long long need = wgs * ctx->n_pad;
+    if (need > ctx->xc_elems) {
+        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
+        ctx->xcbuf = nullptr; ctx->xc_elems = 0;
+        HIP_TRY(hipMalloc(&ctx->xcbuf, (size_t)need * 8));
+        ctx->xc_elems = need;
+    }
+    return MDT_OK;
+}
+
+// the diagnostics of the wave-per-parameter kernel, read behind the test-hooks gate (all zero without it)
+mdtw::Hooks wave_hooks() {
+    mdtw::Hooks h;
+    if (const char* e = hook("MDT_WAVE_WAVES")) h.waves = atoi(e);
+    if (const char* e = hook("MDT_WAVE_TAB")) h.tab_mode = atoi(e);
+    if (const char* e = hook("MDT_WAVE_STOP")) h.stop = atoi(e);
+    if (const char* e = hook("MDT_WAVE_DBG")) h.dbg = (unsigned*)strtoull(e, nullptr, 0); // (only a -DWV_DEBUG / -DWV_PROF build of mdt_wave.hip stores through it)
+    return h;
+}
 
 int ensure_scratch(mdt_ctx* ctx, long long n, long long wgs) {
     const long long n_pad = ((n + 63) / 64) * 64;
@@ -527,6 +547,26 @@ struct Req {
     int keep_status = 0; // second pass of a two-pass request: the flags of the first pass are still to be reported
 };
 
+// n = draws * chains without overflow; false: beyond what the ranking can index (10^9 values per parameter)
+bool slice_size(long long D, long long C, long long* n) {
+    const long long lim = 2000000000LL / 2;
+    if (D < 0 || C < 0 || D > lim || C > lim) return false;
+    *n = D * C; // (<= 10^18)
+    return *n <= lim;
+}
+// The shape half of the dispatch rules -- which kernel family a (slice, parameter count) can be handed to -- shared by run() and
+// mdt_ctx_reserve, so that a reservation allocates what the request will use and nothing else.
+// Wave-per-parameter kernel (mdt_wave.hip): the slice fits it AND there are enough parameters to keep ~3000 waves busy for a few
+// tickets each (measured crossovers: run()).
+bool wave_shape_fits(long long n, long long niter, long long m) {
+    return n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER;
+}
+bool wave_shape_pays(long long n, long long niter, long long P) {
+    return P >= ((n > 4096 || niter > (long long)mdtw::WV_NITER_SHORT) ? 3 * n : 700 + (4 * n) / 3);
+}
+// tickets by measured cost (order_kernel): only when a workgroup gets more than one ticket
+bool lpt_shape(long long P, long long wgs) { return P > wgs && P < 0xFFFFFFFFLL; }
+
 int run_multi(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq);
 int run_host_blocks(mdt_ctx* ctx, const mdt_args* a, const void* x, const Req& rq, int nb);
 void shard_bounds(long long P, int i, int n, long long* lo, long long* hi);
@@ -544,7 +584,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     if (P == 0) return MDT_OK;
     if (!x) return fail(ctx, MDT_EARG, "x is NULL");
     if (D == 0 || C == 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
-    const long long n = D * C, niter = D / s, m = C * s;
+    long long n = 0;
+    if (!slice_size(D, C, &n)) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
+    const long long niter = D / s, m = C * s;
     // layout: x[d + cs * c + ps * p]; 0 = dense
     const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : n;
     if (cs < D || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
@@ -626,10 +668,9 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
     // (split chains of more than 640 draws take the longer per-wave LDS block -- 10 waves beside a 4000-value table --: 2000 x 2 ties at
     // 8000 parameters and wins 15 % at 16 000)
-    const bool wave_pays = P >= ((n > 4096 || niter > (long long)mdtw::WV_NITER_SHORT) ? 3 * n : 700 + (4 * n) / 3);
+    const bool wave_pays = wave_shape_pays(n, niter, P);
     const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
-                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) &&
-                      n >= 256 && n <= (long long)mdtw::WV_MAXN && m <= mdtw::WV_MAXM && niter >= 8 && niter <= (long long)mdtw::WV_NITER &&
+                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) && wave_shape_fits(n, niter, m) &&
                       maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&
                       !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2) && P < 0x7FFFFFFFLL;
 
@@ -675,11 +716,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     int rc = ensure_scratch(ctx, (many && 2 * m > n) ? 2 * m : n, wgs); // (many split chains: their 2 m moments live in the scratch of the sorted copy)
     if (rc) return rc;
     mdtw::Geo wgeo{};
+    mdtw::Hooks whk; // (by value through geometry() and launch(): the wave unit keeps no state of its own)
     int wave_wgs = 0;
     if (wave) {
-        mdtw::set_debug_waves(hook("MDT_WAVE_WAVES") ? atoi(hook("MDT_WAVE_WAVES")) : 0);
-        mdtw::set_tab_mode(hook("MDT_WAVE_TAB") ? atoi(hook("MDT_WAVE_TAB")) : 0);
-        wgeo = mdtw::geometry(n, niter, f32 ? 1 : 0);
+        whk = wave_hooks();
+        wgeo = mdtw::geometry(n, niter, f32 ? 1 : 0, whk);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         wave_wgs = (int)std::min<long long>(ncu, (P + wgeo.waves - 1) / wgeo.waves);
         // (the scratch is sized for a full grid: the same buffer serves every request of the shape)
@@ -699,16 +740,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
             ctx->fb_cap = P;
         }
     }
-    if (strided) {
-        const long long need = wgs * ctx->n_pad;
-        if (need > ctx->xc_elems) {
-            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
-            if (ctx->xcbuf) (void)hipFree(ctx->xcbuf);
-            ctx->xcbuf = nullptr; ctx->xc_elems = 0;
-            HIP_TRY(hipMalloc(&ctx->xcbuf, (size_t)need * 8));
-            ctx->xc_elems = need;
-        }
-    }
+    if (strided) { if (int rcx = ensure_xcbuf(ctx, wgs)) return rcx; }
     const bool need_rank = !rq.basic || rq.mode == 3;
     if (need_rank) {
         rc = ensure_ztab(ctx, n, f32 ? 1 : 0, st);
@@ -812,7 +844,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     kp.prof = ctx->prof;
     // ticket order: by the durations the previous launch with as many parameters measured; this launch measures again
     kp.order = nullptr; kp.cost = nullptr;
-    const bool lpt = !wave && P > wgs && P < 0xFFFFFFFFLL && !hook("MDT_NO_ORDER"); // (one ticket per workgroup at most: nothing to order)
+    const bool lpt = !wave && lpt_shape(P, wgs) && !hook("MDT_NO_ORDER"); // (one ticket per workgroup at most: nothing to order)
     if (lpt) {
         if (P > ctx->order_cap) {
             if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
@@ -843,14 +875,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
         // the wave-per-parameter kernel over all parameters, then the general kernel over the list it left (its length is only
         // known on the device: the second slot's parameter count is patched there); both on the stream, nothing returns to the host
         hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status & 1);
-        mdtw::set_debug_buf(hook("MDT_WAVE_DBG") ? (unsigned*)strtoull(hook("MDT_WAVE_DBG"), nullptr, 0) : nullptr);
-        mdtw::set_debug_stop(hook("MDT_WAVE_STOP") ? atoi(hook("MDT_WAVE_STOP")) : 0);
-        mdtw::launch(st, (const KP*)slot, f32 ? 1 : 0, wgeo, wave_wgs, ctx->wv_scratch, ctx->fb_list, ctx->status + 3);
+        mdtw::launch(st, (const KP*)slot, f32 ? 1 : 0, wgeo, wave_wgs, ctx->wv_scratch, ctx->fb_list, ctx->status + 3, whk);
         KP kb = kp;
         kb.order = ctx->fb_list; kb.cost = nullptr; kb.P = 0;
         KP* slot2 = ctx->kp_ring + (ctx->kp_next++ % KP_RING);
-        hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot2, kb, ctx->status, 3);
-        hipLaunchKernelGGL(fb_patch_kernel, dim3(1), dim3(64), 0, st, slot2, (const int*)ctx->status);
+        hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot2, kb, ctx->status, 3 | 4);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(nthreads), ldsb, st, (const KP*)slot2);
     } else {
         hipLaunchKernelGGL(kp_setup_kernel, dim3(1), dim3(64), 0, st, slot, kp, ctx->status, rq.keep_status & 1);
@@ -1107,7 +1136,7 @@ int mdt_ctx_create(mdt_ctx** out, int device_id) {
             return MDT_ERUNTIME;
         }
     }
-    if (mdtw::prepare_device() != 0) {
+    if (mdtw::kp_bytes() != sizeof(KP) || mdtw::prepare_device() != 0) { // (a variant build that linked a stale partner unit: another KP layout)
         (void)hipFree(ctx->status);
         delete ctx;
         return MDT_ERUNTIME;
@@ -1146,8 +1175,15 @@ int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
     }
     if (a->dtype != MDT_F64 && a->dtype != MDT_F32) return fail(ctx, MDT_EARG, "dtype must be MDT_F64 or MDT_F32");
     if (a->draws <= 0 || a->chains <= 0 || a->params < 0) return fail(ctx, MDT_EDIM, "empty sample dimensions");
-    const long long n = a->draws * a->chains, P = a->params;
-    if (n > 2000000000LL / 2) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large");
+    if (a->location != MDT_HOST && a->location != MDT_DEVICE) return fail(ctx, MDT_EARG, "bad location");
+    long long n = 0;
+    if (!slice_size(a->draws, a->chains, &n)) return fail(ctx, MDT_EUNSUPPORTED, "draws*chains too large"); // (checked before the product is formed)
+    const long long D = a->draws, P = a->params;
+    const long long s = a->split_chains >= 1 ? a->split_chains : 2, niter = D / s, m = a->chains * s; // (0: the keyword's default)
+    const long long cs = a->chain_stride ? a->chain_stride : D, ps = a->param_stride ? a->param_stride : n;
+    if (cs < D || ps < 1) return fail(ctx, MDT_EARG, "chain_stride must be >= draws and param_stride >= 1 (the draws of a chain are contiguous)");
+    const bool strided = cs != D || ps != n;
+    const size_t ts = tsize(a->dtype);
     MDT_ON_DEVICE(ctx);
     hipStream_t st = (hipStream_t)a->stream;
     if (ctx->used && ctx->last_stream != st) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
@@ -1155,9 +1191,13 @@ int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
     const long long wgs = n <= 12288 ? 2LL * ctx->grid : ctx->grid;
     if (int rc = ensure_scratch(ctx, n, wgs)) return rc;
     if (int rc = ensure_ztab(ctx, n, a->dtype == MDT_F32 ? 1 : 0, st)) return rc;
-    if (n >= 256 && n <= (long long)mdtw::WV_MAXN) {
-        // (the block of short split chains holds the most waves: the scratch is sized for those)
-        const mdtw::Geo g = mdtw::geometry(n, 1, a->dtype == MDT_F32 ? 1 : 0);
+    if (strided) { if (int rc = ensure_xcbuf(ctx, wgs)) return rc; } // (MCMCChains storage: the per-workgroup dense copy of a parameter)
+    // the same shape predicates as run(): the wave-per-parameter kernel's scratch and list only when such a request would be handed
+    // to it, the ticket tables only when a workgroup gets more than one ticket
+    const bool wave = wave_shape_fits(n, niter, m) && wave_shape_pays(n, niter, P);
+    if (wave) {
+        const mdtw::Hooks whk = wave_hooks();
+        const mdtw::Geo g = mdtw::geometry(n, niter, a->dtype == MDT_F32 ? 1 : 0, whk);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         const size_t need = mdtw::scratch_bytes(g, (long long)ncu * g.waves);
         if (need > ctx->wv_cap) {
@@ -1167,15 +1207,16 @@ int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
             HIP_TRY(hipMalloc(&ctx->wv_scratch, need));
             ctx->wv_cap = need;
         }
+        if (P > ctx->fb_cap) {
+            if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+            if (ctx->fb_list) (void)hipFree(ctx->fb_list);
+            ctx->fb_list = nullptr; ctx->fb_cap = 0;
+            HIP_TRY(hipMalloc((void**)&ctx->fb_list, (size_t)std::max<long long>(P, 1) * sizeof(unsigned int)));
+            ctx->fb_cap = P;
+        }
     }
-    if (P > ctx->fb_cap && n <= (long long)mdtw::WV_MAXN) {
-        if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
-        if (ctx->fb_list) (void)hipFree(ctx->fb_list);
-        ctx->fb_list = nullptr; ctx->fb_cap = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->fb_list, (size_t)std::max<long long>(P, 1) * sizeof(unsigned int)));
-        ctx->fb_cap = P;
-    }
-    if (P > ctx->order_cap && P < 0xFFFFFFFFLL) {
+    // (a request the wave kernel takes draws no ordered tickets; the grid of the request is wgs or half of it: the smaller one decides)
+    if (!wave && lpt_shape(P, std::min<long long>(wgs, ctx->grid / 2)) && P > ctx->order_cap) {
         if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
         if (ctx->cost) (void)hipFree(ctx->cost);
         if (ctx->order) (void)hipFree(ctx->order);
@@ -1185,6 +1226,15 @@ int mdt_ctx_reserve(mdt_ctx* ctx, const mdt_args* a) {
         HIP_TRY(hipMalloc((void**)&ctx->order, (size_t)P * sizeof(unsigned int)));
         HIP_TRY(hipMalloc((void**)&ctx->order_sorted, (size_t)P * sizeof(unsigned int)));
         ctx->order_cap = P;
+    }
+    // host arrays below the block pipeline's threshold are staged whole: input and the output vectors (larger ones travel in
+    // blocks of the params axis through buffers of their own -- run_host_blocks -- beside a PCIe copy that dwarfs their allocation)
+    if (a->location == MDT_HOST && P > 0) {
+        const size_t xb = (size_t)((P - 1) * ps + (a->chains - 1) * cs + D) * ts;
+        if (xb < ((size_t)128 << 20)) {
+            if (int rc = stage_x_bytes(ctx, xb)) return rc;
+            if (int rc = stage_out_bytes(ctx, 6 * (size_t)P * ts)) return rc;
+        }
     }
     ctx->last_stream = st;
     ctx->used = true;

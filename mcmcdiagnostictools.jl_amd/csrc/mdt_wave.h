@@ -22,18 +22,25 @@ struct Geo {
     int lds_bytes;      // dynamic LDS of the launch
     long long npad;     // elements of per-wave scratch
 };
-Geo geometry(long long n, long long niter, int f32);
+// Diagnostics of a request (read by the caller behind the MDT_TEST_HOOKS gate of mdt_hip.hip and handed over BY VALUE: the unit
+// keeps no mutable state, so contexts on several threads -- the workers of a multi-GPU context, stream contexts -- never share any).
+struct Hooks {
+    int waves = 0;      // at most this many waves per workgroup (0 = what the LDS allows; MDT_WAVE_WAVES)
+    int tab_mode = 0;   // 0: the rule of geometry(), 1: score table always in LDS, 2: never (MDT_WAVE_TAB)
+    int stop = 0;       // parameters end after phase k (0 = never; MDT_WAVE_STOP)
+    unsigned* dbg = nullptr; // progress word per wave in host-pinned memory; honoured by -DWV_DEBUG / -DWV_PROF builds only (MDT_WAVE_DBG)
+};
+Geo geometry(long long n, long long niter, int f32, const Hooks& hk = Hooks());
 // bytes of per-wave scratch in global memory for `waves_total` waves
 size_t scratch_bytes(const Geo& g, long long waves_total);
-void set_debug_buf(unsigned* host_pinned); // diagnostics: progress word per wave
-void set_debug_waves(int w); // diagnostics: at most w waves per workgroup (0 = what the LDS allows)
-void set_tab_mode(int t);    // diagnostics: 0 the rule, 1 score table always in LDS, 2 never
-void set_debug_stop(int k); // diagnostics: parameters end after phase k (0 = never)
+// sizeof(KP) as this unit was compiled: mdt_ctx_create compares it with its own (a variant build that links a stale partner unit
+// -- tools/build_variant.sh -- would otherwise read a parameter block of another layout)
+size_t kp_bytes();
 int prepare_device(); // once per device, under its hipSetDevice: 0 = ok
 // Queue the kernel on `st`: workgroups x waves tickets over kp->P parameters.  `kp_slot` is the device copy of the parameter
 // block (kp_setup_kernel wrote it on the same stream).  Parameters the path cannot serve (a non-finite value, a point mass
 // larger than a round, too many ties among the folded values) are appended to fb_list, their count to *fb_count.
 void launch(hipStream_t st, const mdtc::KP* kp_slot, int f32, const Geo& g, int workgroups, void* scratch,
-            unsigned* fb_list, int* fb_count);
+            unsigned* fb_list, int* fb_count, const Hooks& hk = Hooks());
 
 } // namespace mdtw

@@ -1318,7 +1318,12 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indic
 }
 
 // ------------------------------------------------------------------ the kernel
+// (progress words in host-pinned memory: diagnostics builds only -- tools/build_wave_variant.sh NAME -DWV_DEBUG, tools/dev_wave_dbg.py)
+#if defined(WV_DEBUG) || defined(WV_PROF)
 #define WDBG(code) do { if (wa.dbg && lane == 0) __hip_atomic_store(wa.dbg + gw, (unsigned)(code), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); } while (0)
+#else
+#define WDBG(code) do { } while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ kpp, WvArgs wa) {
     const WV_CA KP& kp = *(const WV_CA KP*)(unsigned long long)kpp;
@@ -1430,22 +1435,19 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
 }
 
 // ------------------------------------------------------------------ host side
-static int g_debug_waves = 0;
-void set_debug_waves(int w) { g_debug_waves = w; }
-static int g_tab_mode = 0; // 0: by the rule below; 1: always in LDS; 2: never (diagnostics, MDT_WAVE_TAB)
-void set_tab_mode(int t) { g_tab_mode = t; }
+size_t kp_bytes() { return sizeof(KP); }
 
-Geo geometry(long long n, long long niter, int f32) {
+Geo geometry(long long n, long long niter, int f32, const Hooks& hk) {
     Geo g;
     g.tab_bytes = (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16);
     // above 4096 values the table (64 KB at 8000) would leave 8 waves per CU: the series phase then reads its entries from the dense
     // global copy instead (L2) and the workgroup keeps its 12 waves -- 1000 x 8 x 50 000: 13.6 -> 13.2 ms; below, the LDS table is the
     // faster one by 0.5 - 2 % (round 5, MDT_WAVE_TAB = 1 / 2 forces either)
-    if (g_tab_mode == 2 || (g_tab_mode == 0 && n > 4096)) g.tab_bytes = 0;
+    if (hk.tab_mode == 2 || (hk.tab_mode == 0 && n > 4096)) g.tab_bytes = 0;
     g.perwave = niter <= WV_NITER_SHORT ? PERWAVE_SHORT : PERWAVE;
     int wv = (LDS_TOTAL - g.tab_bytes) / g.perwave;
     if (wv > NTHREADS / 64) wv = NTHREADS / 64;
-    if (g_debug_waves > 0 && g_debug_waves < wv) wv = g_debug_waves; // diagnostics (MDT_WAVE_WAVES): fewer waves per workgroup
+    if (hk.waves > 0 && hk.waves < wv) wv = hk.waves; // diagnostics (MDT_WAVE_WAVES): fewer waves per workgroup
     if (wv < 1) wv = 1;
     g.waves = wv;
     g.lds_bytes = g.tab_bytes + wv * g.perwave;
@@ -1463,12 +1465,8 @@ int prepare_device() { // > 64 KB of dynamic LDS needs the opt-in, per kernel an
     return 0;
 }
 
-static int g_debug_stop = 0;
-static unsigned* g_debug_buf = nullptr;
-void set_debug_stop(int k) { g_debug_stop = k; }
-void set_debug_buf(unsigned* p) { g_debug_buf = p; }
-
-void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgroups, void* scratch, unsigned* fb_list, int* fb_count) {
+void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgroups, void* scratch, unsigned* fb_list, int* fb_count,
+            const Hooks& hk) {
     const long long waves_total = (long long)workgroups * g.waves;
     WvArgs wa;
     wa.rec = (Rec*)scratch;
@@ -1478,8 +1476,12 @@ void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgr
     wa.npad = g.npad;
     wa.tab_bytes = g.tab_bytes;
     wa.perwave = g.perwave;
-    wa.stop = g_debug_stop;
-    wa.dbg = g_debug_buf;
+    wa.stop = hk.stop;
+#if defined(WV_DEBUG) || defined(WV_PROF)
+    wa.dbg = hk.dbg; // (diagnostics builds only: a release library never stores through a pointer that came from the environment)
+#else
+    wa.dbg = nullptr;
+#endif
     if (f32) hipLaunchKernelGGL(wave_kernel<float>, dim3((unsigned)workgroups), dim3((unsigned)(64 * g.waves)), (size_t)g.lds_bytes, st, kp_slot, wa);
     else hipLaunchKernelGGL(wave_kernel<double>, dim3((unsigned)workgroups), dim3((unsigned)(64 * g.waves)), (size_t)g.lds_bytes, st, kp_slot, wa);
 }

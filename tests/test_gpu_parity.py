@@ -1717,6 +1717,38 @@ def test_reserve_changes_no_bits_and_validates_like_a_request(pkg):
         pkg.reserve(0, 4, 10)
     with pytest.raises(Exception):
         pkg.reserve(1 << 20, 1 << 11, 1)  # draws x chains beyond the ranking's index range
+    with pytest.raises(Exception):
+        pkg.reserve(1 << 40, 1 << 40, 1)  # ... and a product that would overflow int64 (checked before it is formed)
+
+
+def test_reserve_like_resolves_the_context_of_the_request(pkg):
+    """reserve(like=array) warms exactly the context the request on that array resolves to (round-5 advisor: without it a host request
+    -- context (0, 0) -- or a request under another stream found a cold context), announces its layout (MCMCChains storage: the
+    per-workgroup gather buffer) and its location (host arrays: the staging buffers), and changes no bits."""
+    import torch
+    rng = np.random.default_rng(32)
+    D, C, P = 600, 4, 30
+    x = ar1(0.3, D, C, P, rng)
+    # a host request: the context of (device 0, stream 0), whatever the current stream is
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        pkg.reserve(0, 0, 0, like=x)
+        got_host = [np.asarray(o) for o in pkg.bulk_tail(x)]
+    assert pkg.api._ctx_key(pkg.api._describe(x)) == (0, 0)
+    # MCMCChains storage (iterations, parameters, chains) on the device, read in place
+    xm = torch.from_numpy(np.ascontiguousarray(np.transpose(x, (1, 2, 0)))).cuda()  # memory: chains outermost, draws fastest
+    view = xm.permute(2, 0, 1)                                                      # (draws, chains, params), strided
+    d = pkg.api._describe(view)
+    assert (d.D, d.C, d.P) == (D, C, P) and d.cs == D * P and d.ps == D
+    st2 = torch.cuda.Stream()
+    with torch.cuda.stream(st2):
+        pkg.reserve(0, 0, 0, like=view)
+        got_str = [o.cpu().numpy() for o in pkg.bulk_tail(view)]
+    st2.synchronize()
+    ref = [o.cpu().numpy() for o in pkg.bulk_tail(dev(x))]
+    for a, b, c in zip(got_host, got_str, ref):
+        np.testing.assert_array_equal(a, c)
+        np.testing.assert_array_equal(b, c)
 
 
 def test_chain_lengths_between_the_lds_resident_and_the_windowed_series(pkg, methods):
