@@ -833,6 +833,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     { const char* fm = hook("MDT_FOLD_MERGE"); kp.fold_merge = fm ? atoi(fm) : 1; }
     { const char* wo = hook("MDT_WINOUT"); kp.winout = wo ? atoi(wo) : 1; }
     { const char* pe = hook("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
+    { const char* te = hook("MDT_TAIL_SRT"); kp.tail_srt = te ? atoi(te) : 1; }
     kp.onechunk = onechunk ? 1 : 0;
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];

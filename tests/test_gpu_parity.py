@@ -544,6 +544,51 @@ def test_context_registry_pins_and_never_drops_flags(pkg):
     torch.cuda.synchronize()
 
 
+def test_tail_only_request_takes_the_merge_and_changes_no_bit(pkg, monkeypatch):
+    """Round 6: a tail-only request that needs R-hat -- ess_rhat(kind = tail), rhat(kind = tail) -- ranks every round of x for the
+    sorted copy (no score is looked up or written) and folds by the merge of fold_merge_phase, as the fused request does, instead of
+    an order-statistics-only ranking followed by a second FULL ranking of |x - median| (src/utils.jl:148-158, src/ess_rhat.jl:301-311,
+    335-420).  MDT_TAIL_SRT=0 is the former route: the same bits on continuous data, ties, an odd number of draws (rows dropped
+    by the split), Float32, 16 chains, an infinity (which sends the fold down the general ranking by itself), in the
+    workgroup-per-parameter geometries; and the results are those of the fused request and of the oracle."""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(61)
+    monkeypatch.setenv("MDT_WAVE", "0")  # (the wave-per-parameter kernel has its own path for these shapes and its own tests)
+    cases = []
+    x = ar1(0.5, 4000, 4, 12, rng)
+    x[:, :, 3] = np.round(x[:, :, 3], 1)           # heavy ties
+    x[9, 2, 5] = np.inf                            # (a NaN under a quantile is an ArgumentError, as in the reference: not here)
+    cases.append(("f64 4 chains", x))
+    cases.append(("config-2 slice", ar1(0.3, 10000, 4, 3, rng)))
+    cases.append(("odd draws", ar1(0.2, 3001, 4, 5, rng)))
+    cases.append(("f32 16 chains", ar1(0.3, 1500, 16, 6, rng).astype(np.float32)))
+    cases.append(("short", ar1(0.6, 600, 4, 9, rng)))
+    for what, x in cases:
+        xd = dev(x)
+        outs = {}
+        for sw in ("1", "0"):
+            monkeypatch.setenv("MDT_TAIL_SRT", sw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                e, r = pkg.ess_rhat(xd, kind="tail")
+                outs[sw] = [host(e), host(r), host(pkg.rhat(xd, kind="tail")), host(pkg.ess(xd, kind="tail"))]
+        monkeypatch.delenv("MDT_TAIL_SRT", raising=False)
+        for a, b in zip(outs["1"], outs["0"]):
+            assert np.array_equal(a, b, equal_nan=True), what
+        assert np.array_equal(outs["1"][1], outs["1"][2], equal_nan=True), what + ": rhat(tail) == ess_rhat(tail).rhat"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            fused = [host(o) for o in pkg.bulk_tail(xd)]
+            want = co.bulk_tail(np.asarray(x, dtype=np.float64)) if x.dtype == np.float64 else None
+        assert np.array_equal(outs["1"][1], fused[3], equal_nan=True), what + ": R-hat tail of the fused request"
+        tol = RTOL64 if x.dtype == np.float64 else 2e-5
+        assert_close(outs["1"][0], fused[1], tol, what + ": ESS tail of the fused request")
+        if want is not None:
+            assert_close(outs["1"][0], want[1], RTOL64, what + ": ESS tail against the oracle")
+            assert_close(outs["1"][1], want[3], RTOL64, what + ": R-hat tail against the oracle")
+
+
 def test_tile_major_partition_and_ticket_order_change_no_bit(pkg, monkeypatch):
     """Round 3: the tile-major partition (one pass instead of histogram + partition, MDT_PA=0 switches it off) and the
     cost-ordered tickets of the persistent launch (MDT_NO_ORDER=1 switches them off) must not change a single bit of

@@ -18,6 +18,8 @@ x = synth(D, C, P, torch.device("cuda", 0), 1234).permute(2, 1, 0)
 warnings.simplefilter("ignore")
 calls = [("ess_rhat basic", lambda: pkg.ess_rhat(x, kind="basic")), ("rhat basic", lambda: pkg.rhat(x, kind="basic")),
          ("ess_rhat bulk", lambda: pkg.ess_rhat(x, kind="bulk")), ("ess_rhat tail", lambda: pkg.ess_rhat(x, kind="tail")),
+         ("ess tail", lambda: pkg.ess(x, kind="tail")), ("rhat tail", lambda: pkg.rhat(x, kind="tail")),
+         ("ess bulk", lambda: pkg.ess(x, kind="bulk")), ("rhat bulk", lambda: pkg.rhat(x, kind="bulk")),
          ("ess_rhat rank", lambda: pkg.ess_rhat(x, kind="rank")), ("rhat rank", lambda: pkg.rhat(x, kind="rank")),
          ("bulk_tail", lambda: pkg.bulk_tail(x)), ("ess median", lambda: pkg.ess(x, kind=np.median)),
          ("ess mad", lambda: pkg.ess(x, kind="mad")), ("ess std", lambda: pkg.ess(x, kind=np.std)),
