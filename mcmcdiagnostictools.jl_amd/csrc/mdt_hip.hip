@@ -564,6 +564,11 @@ bool wave_shape_fits(long long n, long long niter, long long m) {
 bool wave_shape_pays(long long n, long long niter, long long P) {
     return P >= ((n > 4096 || niter > (long long)mdtw::WV_NITER_SHORT) ? 3 * n : 700 + (4 * n) / 3);
 }
+// ... and for raw draws (kind = basic, mcse(mean); round 6).  Measured crossovers (profiles/r06_wave_raw_crossover.txt; ms, wave kernel /
+// workgroup-per-parameter kernels): with the autocovariance 1000 x 4 at ~7000 parameters (4000: 0.42 / 0.34, 8000: 0.49 / 0.53, 100 000:
+// 2.40 / 4.70), 250 x 4 at ~2000 (0.22 / 0.22; 200 000: 2.60 / 8.22), 1000 x 8 at ~8000 (0.93 / 0.95; 50 000: 3.09 / 4.73); R-hat alone
+// from ~2000 parameters at every shape (1000 x 4 x 100 000: 1.37 / 3.54)
+bool wave_raw_pays(long long n, long long P, bool acov) { return P >= (acov ? 1500 + n : 2000); }
 // tickets by measured cost (order_kernel): only when a workgroup gets more than one ticket
 bool lpt_shape(long long P, long long wgs) { return P > wgs && P < 0xFFFFFFFFLL; }
 
@@ -668,8 +673,12 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const int wave_env = hook("MDT_WAVE") ? atoi(hook("MDT_WAVE")) : 1;
     // (split chains of more than 640 draws take the longer per-wave LDS block -- 10 waves beside a 4000-value table --: 2000 x 2 ties at
     // 8000 parameters and wins 15 % at 16 000)
-    const bool wave_pays = wave_shape_pays(n, niter, P);
-    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && rq.mode == 0 && !rq.basic && rq.est == 0 &&
+    // Round 6: raw draws too -- ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) (no row dropped by the split: its pooled
+    // standard deviation then follows from the split-chain moments) -- through the series phase of the same kernel, no ranking, no
+    // per-wave scratch.  R-hat is the same bits as on the workgroup-per-parameter kernels (the same summation order).
+    const bool wave_raw = rq.basic && rq.est == 0 && (rq.mode == 0 || (rq.mode == 2 && D % s == 0)) && (rq.need_eb || rq.need_rb);
+    const bool wave_pays = wave_raw ? wave_raw_pays(n, P, rq.need_eb && ess_ok) : wave_shape_pays(n, niter, P);
+    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && ((rq.mode == 0 && !rq.basic) || wave_raw) && rq.est == 0 &&
                       (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt) && wave_shape_fits(n, niter, m) &&
                       maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&
                       !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2) && P < 0x7FFFFFFFLL;
@@ -720,11 +729,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     int wave_wgs = 0;
     if (wave) {
         whk = wave_hooks();
-        wgeo = mdtw::geometry(n, niter, f32 ? 1 : 0, whk);
+        wgeo = mdtw::geometry(n, niter, f32 ? 1 : 0, whk, wave_raw ? 1 : 0);
         const int ncu = ctx->num_cu > 0 ? ctx->num_cu : 256;
         wave_wgs = (int)std::min<long long>(ncu, (P + wgeo.waves - 1) / wgeo.waves);
-        // (the scratch is sized for a full grid: the same buffer serves every request of the shape)
-        const size_t need = mdtw::scratch_bytes(wgeo, (long long)ncu * wgeo.waves);
+        // (the scratch is sized for a full grid: the same buffer serves every request of the shape; raw draws pass through none)
+        const size_t need = wave_raw ? 0 : mdtw::scratch_bytes(wgeo, (long long)ncu * wgeo.waves);
         if (need > ctx->wv_cap) {
             if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream));
             if (ctx->wv_scratch) (void)hipFree(ctx->wv_scratch);

@@ -30,7 +30,7 @@ struct Hooks {
     int stop = 0;       // parameters end after phase k (0 = never; MDT_WAVE_STOP)
     unsigned* dbg = nullptr; // progress word per wave in host-pinned memory; honoured by -DWV_DEBUG / -DWV_PROF builds only (MDT_WAVE_DBG)
 };
-Geo geometry(long long n, long long niter, int f32, const Hooks& hk = Hooks());
+Geo geometry(long long n, long long niter, int f32, const Hooks& hk = Hooks(), int raw = 0); // raw: a raw-draw request (no score table)
 // bytes of per-wave scratch in global memory for `waves_total` waves
 size_t scratch_bytes(const Geo& g, long long waves_total);
 // sizeof(KP) as this unit was compiled: mdt_ctx_create compares it with its own (a variant build that links a stale partner unit

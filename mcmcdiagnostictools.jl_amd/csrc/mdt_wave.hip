@@ -210,6 +210,24 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) { // total in eve
     const int lo = __builtin_amdgcn_readlane((int)v, 63), hi = __builtin_amdgcn_readlane((int)(v >> 32), 63);
     return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
+// The wave-wide double sum of mdt_device.hpp (wave_sum there), instruction for instruction: the same association order is what makes
+// the raw-draw moments below the same bits as the workgroup-per-parameter kernels'.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, true);
+    return v + __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v) { // total in every lane
+    v = dpp_add_d<0x111, 0xF>(v); // row_shr:1
+    v = dpp_add_d<0x112, 0xF>(v); // row_shr:2
+    v = dpp_add_d<0x114, 0xF>(v); // row_shr:4
+    v = dpp_add_d<0x118, 0xF>(v); // row_shr:8
+    v = dpp_add_d<0x142, 0xA>(v); // row_bcast:15
+    v = dpp_add_d<0x143, 0xC>(v); // row_bcast:31
+    return readlane_d(v, 63);
+}
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)v, o); v = t > v ? t : v; }
@@ -935,7 +953,13 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
 // accumulated over the chains; Geyer's initial monotone sequence (:555-594) between blocks of 32 lags.  While a chain is
 // staged its tail-ESS indicator words are taken from the ranks (x <= q <=> doubled rank <= r2q).
 // (NB: rows of 64 draws the code is unrolled for -- 4, 8, 10 or 16: the kernel picks the smallest that holds a split chain; 16 rows need the longer per-wave block)
-template <typename T, int NB> __device__ __attribute__((noinline)) void ph_series(unsigned wbase_arg) {
+// RAW (round 6): the series are the raw draws themselves (kind = basic, mcse(kind = mean): src/ess_rhat.jl:438-603, src/mcse.jl:45-51) --
+// no ranking comes first, a split chain is read from x in time order; its moments are plain double sums taken in the order of the
+// workgroup-per-parameter kernels (series_z_phase<RAW>: 1024 virtual threads, element i to thread i mod 1024, wave sums per virtual
+// wave, the virtual waves added in index order -- with at most 1024 draws per split chain every virtual thread holds ONE draw, so a
+// wave reproduces that order with one wave sum per row of 64 draws): R-hat is the same bits here and there.  A non-finite draw
+// hands the parameter to the general kernel.
+template <typename T, int NB, bool RAW = false> __device__ __attribute__((noinline)) void ph_series(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* lagA = (WV_LA double*)(wb + OFF_LAGA);
     WV_LA double* mean_j = (WV_LA double*)(wb + OFF_MEAN);
@@ -960,7 +984,7 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
     // indicator words behind the stage, when both fit the view
     const int nwS = (int)nblk, nwU = nwS + (int)(maxlag >> 6) + 2;
     const unsigned stg_doubles = 64u * nblk + 272u;
-    const bool bits = kp.need_et && kp.ess_ok && rfl(ws->zq_ok) != 0 && (int)(stg_doubles * 8u) + 2 * m * nwU * 8 <= (int)rflu(ws->view_bytes);
+    const bool bits = !RAW && kp.need_et && kp.ess_ok && rfl(ws->zq_ok) != 0 && (int)(stg_doubles * 8u) + 2 * m * nwU * 8 <= (int)rflu(ws->view_bytes);
     WV_LA unsigned long long* sb2 = (WV_LA unsigned long long*)(stage + stg_doubles);
     const unsigned r2q0 = rflu(ws->r2q[0]), r2q1 = rflu(ws->r2q[1]);
     if (bits) { for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull; }
@@ -972,13 +996,28 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
     bool started = false, done = false;
     long long k0 = 0;
     int block = 0;
-    unsigned rn[NB];
-    auto issue = [&](int j) { // the rank list of split chain j: all its rows in flight
-        const WV_GA unsigned* rj = rl + (unsigned)j * niter;
+    unsigned rn[RAW ? 1 : NB];
+    T xn[RAW ? NB : 1];
+    const WV_GA T* xpr = (const WV_GA T*)rfl64(ws->xp);
+    const unsigned us_ = (unsigned)kp.s, urem_ = (unsigned)kp.rem;
+    const long long cs_ = kp.cstride;
+    unsigned bad = 0u;
+    auto issue = [&](int j) { // the rank list of split chain j (RAW: its draws): all its rows in flight
+        if constexpr (RAW) {
+            const unsigned c = (unsigned)j / us_, kk = (unsigned)j - c * us_;
+            const WV_GA T* xj = xpr + ((long long)c * cs_ + (long long)(kk * niter + (kk < urem_ ? kk : urem_))); // src/utils.jl:29-36
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const unsigned t = 64u * (unsigned)b + (unsigned)lane;
-            rn[b] = rj[t < niter ? t : niter - 1u];
+            for (int b = 0; b < NB; ++b) {
+                const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                xn[b] = xj[t < niter ? t : niter - 1u];
+            }
+        } else {
+            const WV_GA unsigned* rj = rl + (unsigned)j * niter;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                rn[b] = rj[t < niter ? t : niter - 1u];
+            }
         }
     };
     WV_LA unsigned short* rank_t = (WV_LA unsigned short*)stage; // the list in time order (in the bytes of the stage, before the chain is staged)
@@ -994,34 +1033,60 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
         for (int i = 0; i < ZT; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
         issue(0);
         for (int j = 0; j < m; ++j) {
-            unsigned r2[NB];
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { // list -> time order: (draw, rank) pairs scattered in LDS, read back by position
-                const unsigned t = 64u * (unsigned)b + (unsigned)lane;
-                if ((unsigned)b < nblk && t < niter) rank_t[rn[b] & 0xFFFFu] = (unsigned short)(rn[b] >> 16);
-            }
-            if (j + 1 < m) issue(j + 1);
-            lds_fence();
-#pragma unroll
-            for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rank_t[t < niter ? t : niter - 1u]; }
-            lds_fence();
+            unsigned r2[RAW ? 1 : NB];
+            double z[NB];
             double K = 0.0;
             long long a1 = 0, a2 = 0;
             const double mu0 = (block > 0) ? mu_j[j] : 0.0;
-            double z[NB];
+            if constexpr (RAW) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) z[b] = (double)lz[r2[b] >> 1];
-            if (!tab_lds) { // (the shape's table is not in LDS: the same entries from the dense global copy, L2)
+                for (int b = 0; b < NB; ++b) z[b] = (double)xn[b];
+                if (j + 1 < m) issue(j + 1);
+            } else {
 #pragma unroll
-                for (int b = 0; b < NB; ++b) z[b] = (double)gzd_s[r2[b] >> 1];
-            }
-            if (anyodd) { // a half-integer rank: the table by doubled rank
+                for (int b = 0; b < NB; ++b) { // list -> time order: (draw, rank) pairs scattered in LDS, read back by position
+                    const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                    if ((unsigned)b < nblk && t < niter) rank_t[rn[b] & 0xFFFFu] = (unsigned short)(rn[b] >> 16);
+                }
+                if (j + 1 < m) issue(j + 1);
+                lds_fence();
 #pragma unroll
-                for (int b = 0; b < NB; ++b) if (r2[b] & 1u) z[b] = (double)gz[r2[b]];
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; r2[b] = rank_t[t < niter ? t : niter - 1u]; }
+                lds_fence();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) z[b] = (double)lz[r2[b] >> 1];
+                if (!tab_lds) { // (the shape's table is not in LDS: the same entries from the dense global copy, L2)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) z[b] = (double)gzd_s[r2[b] >> 1];
+                }
+                if (anyodd) { // a half-integer rank: the table by doubled rank
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) if (r2[b] & 1u) z[b] = (double)gz[r2[b]];
+                }
             }
             K = readlane_d(z[0], 0);
             double mu = mu0;
-            if (block == 0) {
+            if (RAW && block == 0) {
+                // the sums of series_z_phase<RAW> (mdt_series.inc): virtual wave b holds the draws 64 b ... 64 b + 63 of the chain, one per
+                // virtual thread (s1 = 0 + u, s2 = fma(u, u, 0)); its wave sums; the virtual waves added in index order
+                double S1 = 0.0, S2 = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const unsigned t = 64u * (unsigned)b + (unsigned)lane;
+                    const bool okt = (unsigned)b < nblk && t < niter;
+                    const double u = okt ? z[b] - K : 0.0;
+                    bad |= (okt && !(z[b] - z[b] == 0.0)) ? 1u : 0u;
+                    double s1 = 0.0, s2 = 0.0;
+                    s1 += u;
+                    s2 = fma(u, u, s2);
+                    const double r1 = wave_sum_d(s1), r2s = wave_sum_d(s2);
+                    S1 += r1;
+                    S2 += r2s;
+                }
+                mu = S1 / dn;
+                if (lane == 0) { var_j[j] = (S2 - mu * S1) / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
+            }
+            if (!RAW && block == 0) {
                 // exact integer sums of the shifted scores; the expressions of series_z_phase: bit-identical means and variances
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -1037,7 +1102,7 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
                 if (lane == 0) { var_j[j] = Cc / (double)(niter - 1u); mean_j[j] = K + mu; mu_j[j] = mu; }
                 if (bits) {
 #pragma unroll
-                    for (int b = 0; b < NB; ++b) {
+                    for (int b = 0; b < (RAW ? 0 : NB); ++b) {
                         if ((unsigned)b < nblk) {
                             const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
                             const unsigned long long q0 = __ballot(okt && r2[b] <= r2q0), q1 = __ballot(okt && r2[b] <= r2q1);
@@ -1067,6 +1132,11 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_serie
             }
             lds_fence();
             WPROF(15);
+        }
+        if (RAW && block == 0 && __ballot(bad != 0u) != 0ull) { // a NaN or an infinity among the draws: the general kernel serves the parameter
+            if (lane == 0) ws->fallback = 1;
+            lds_fence();
+            return;
         }
         if (block == 0) wbm = combine_moments(mean_j, var_j, m, kp.cf);
         if (!acov) break;
@@ -1380,6 +1450,38 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         WPROF(0);
         const int stop = wa.stop; // diagnostics: the parameter ends after phase `stop`, its outputs stay NaN
         WDBG(10);
+        if (kp.basic) {
+            // raw draws (round 6): ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) -- no ranking, the series phase alone
+            const unsigned nblk = ((unsigned)kp.niter + 63u) >> 6;
+            if (nblk <= 4u) ph_series<T, 4, true>(wbase);
+            else if (nblk <= 8u) ph_series<T, 8, true>(wbase);
+            else if (nblk <= (unsigned)((WV_NITER_SHORT + 63) / 64)) ph_series<T, (WV_NITER_SHORT + 63) / 64, true>(wbase);
+            else ph_series<T, (WV_NITER + 63) / 64, true>(wbase);
+            if (rfl(ws->fallback) != 0) {
+                if (lane == 0) { const int i = atomicAdd(wa.fb_count, 1); wa.fb_list[i] = (unsigned)p; }
+            } else if (lane == 0) {
+                const double ess = (kp.need_eb && kp.ess_ok) ? ws->out[0] : nan;
+                if (kp.mode == 2) {
+                    // mcse(kind = mean) = pooled corrected std / sqrt(ESS) (src/mcse.jl:45-51); every draw belongs to a split chain here
+                    // (no row dropped by the split), so the pooled moments follow from the split-chain ones -- Chan's combination, the
+                    // expressions of raw_request in mdt_device.hpp
+                    const WV_LA double* mean_j = (const WV_LA double*)(wb + OFF_MEAN);
+                    const WV_LA double* var_j = mean_j + WV_MAXM;
+                    double mu = 0.0;
+                    for (int j = 0; j < kp.m; ++j) mu += mean_j[j];
+                    mu /= (double)kp.m;
+                    double ss = 0.0;
+                    for (int j = 0; j < kp.m; ++j) { const double d = mean_j[j] - mu; ss += (double)(kp.niter - 1) * var_j[j] + (double)kp.niter * d * d; }
+                    store_out<T>(kp.out_eb, p, sqrt(ss / (double)(kp.n - 1)) / sqrt(ess));
+                } else {
+                    store_out<T>(kp.out_eb, p, ess);
+                    store_out<T>(kp.out_rb, p, ws->out[1]);
+                }
+            }
+            WPROF(9);
+            lds_fence(); // (every lane joins before the next ticket: see the end of the loop)
+            continue;
+        }
         ph_classify<T>(wbase);
         bool fb = rfl(ws->fallback) != 0;
         WDBG(20);
@@ -1437,9 +1539,9 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
 // ------------------------------------------------------------------ host side
 size_t kp_bytes() { return sizeof(KP); }
 
-Geo geometry(long long n, long long niter, int f32, const Hooks& hk) {
+Geo geometry(long long n, long long niter, int f32, const Hooks& hk, int raw) {
     Geo g;
-    g.tab_bytes = (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16);
+    g.tab_bytes = raw ? 0 : (int)((((n + 1) * (f32 ? 4 : 8)) + 15) / 16 * 16); // (raw draws are never ranked: no score table)
     // above 4096 values the table (64 KB at 8000) would leave 8 waves per CU: the series phase then reads its entries from the dense
     // global copy instead (L2) and the workgroup keeps its 12 waves -- 1000 x 8 x 50 000: 13.6 -> 13.2 ms; below, the LDS table is the
     // faster one by 0.5 - 2 % (round 5, MDT_WAVE_TAB = 1 / 2 forces either)

@@ -1641,6 +1641,69 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
     assert pkg.status() in (0, 2)
 
 
+def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):
+    """Round 6: raw draws -- ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) (src/ess_rhat.jl:438-603, src/mcse.jl:45-51) -- on
+    short slices through the series phase of the wave-per-parameter kernel (no ranking).  Against the workgroup-per-parameter
+    kernels (MDT_WAVE=0): R-hat the same BITS (the moments are plain double sums taken in the same order: at most 1024 draws per
+    split chain, one per virtual thread), ESS and mcse within 1e-12 (other summation order of the lag products); a NaN or an
+    infinity among the draws comes back through the general kernel inside the same request; the oracle agrees."""
+    import warnings
+    import torch
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(606)
+    x = _wave_case_array(rng)
+    x[3, 1, 5] = np.inf      # (parameters the path hands back)
+    x[40, 0, 7] = np.nan
+    shapes = [("1000x4", x), ("997x4", x[:997]), ("500x4", x[:500]), ("64x4", x[:64]), ("f32", x.astype(np.float32)),
+              ("1000x8", np.concatenate([x, x[::-1]], axis=1)), ("1000x1", x[:, :1]), ("2000x2", np.concatenate([x[:, :2], x[:, 2:]], axis=0))]
+
+    def run_all(xd, s):
+        out = []
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            r = pkg.ess_rhat(xd, kind="basic", split_chains=s)
+            out += [("ess", host(r.ess)), ("rhat", host(r.rhat))]
+            out.append(("rhat only", host(pkg.rhat(xd, kind="basic", split_chains=s))))
+            out.append(("ess only rel", host(pkg.ess(xd, kind="basic", split_chains=s, relative=True, maxlag=30))))
+            out.append(("ess fft", host(pkg.ess(xd, kind="basic", split_chains=s, autocov_method=methods["fft"]))))
+            out.append(("mcse", host(pkg.mcse(xd, split_chains=s))))
+        return out
+
+    for what, xs in shapes:
+        for s in (2, 1, 3):
+            D, C = xs.shape[:2]
+            if C * s > 16 or D // s > 1024 or D // s < 8 or D * C < 256 or D * C > 8192:
+                continue
+            xd = dev(xs)
+            monkeypatch.setenv("MDT_WAVE", "2")
+            a = run_all(xd, s)
+            monkeypatch.setenv("MDT_WAVE", "0")
+            b = run_all(xd, s)
+            monkeypatch.delenv("MDT_WAVE")
+            for (ka, va), (kb, vb) in zip(a, b):
+                if "rhat" in ka:
+                    assert np.array_equal(va, vb, equal_nan=True), (what, s, ka, va, vb)
+                else:
+                    assert_close(va, vb, 1e-12 if xs.dtype == np.float64 else 2e-6, f"{what} s={s} {ka}")
+            if xs.dtype == np.float64:
+                e, r = co.ess_rhat(xs, kind="basic", split_chains=s)
+                assert_close(a[0][1], e, RTOL64, f"{what} s={s} oracle ess")
+                assert_close(a[1][1], r, RTOL64, f"{what} s={s} oracle rhat")
+    # MCMCChains storage (iterations, parameters, chains), read in place
+    xs = x[:, :, :6]
+    D, C, P = xs.shape
+    xm = torch.from_numpy(np.ascontiguousarray(np.transpose(xs, (1, 2, 0)))).cuda()
+    view = xm.permute(2, 0, 1)
+    monkeypatch.setenv("MDT_WAVE", "2")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = [host(pkg.rhat(view, kind="basic")), host(pkg.mcse(view))]
+        b = [host(pkg.rhat(dev(xs), kind="basic")), host(pkg.mcse(dev(xs)))]
+    monkeypatch.delenv("MDT_WAVE")
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v, equal_nan=True)
+
+
 @pytest.mark.parametrize("name", ["cfg1_randn_1000x4x10", "ties_200x4x6", "odd_1001x3x3", "ar1_500x4x10", "onechain_400x1x3"])
 def test_wave_path_on_the_golden_vectors(pkg, methods, monkeypatch, name):
     """the committed golden vectors through the wave-per-parameter kernel, forced wherever it can run (every kind x method x
