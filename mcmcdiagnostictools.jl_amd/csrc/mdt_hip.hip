@@ -457,6 +457,7 @@ mdtw::Hooks wave_hooks() {
     if (const char* e = hook("MDT_WAVE_WAVES")) h.waves = atoi(e);
     if (const char* e = hook("MDT_WAVE_TAB")) h.tab_mode = atoi(e);
     if (const char* e = hook("MDT_WAVE_STOP")) h.stop = atoi(e);
+    if (const char* e = hook("MDT_WAVE_OSONLY")) h.osonly = atoi(e);
     if (const char* e = hook("MDT_WAVE_DBG")) h.dbg = (unsigned*)strtoull(e, nullptr, 0); // (only a -DWV_DEBUG / -DWV_PROF build of mdt_wave.hip stores through it)
     return h;
 }

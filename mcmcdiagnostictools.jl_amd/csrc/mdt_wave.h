@@ -28,6 +28,7 @@ struct Hooks {
     int waves = 0;      // at most this many waves per workgroup (0 = what the LDS allows; MDT_WAVE_WAVES)
     int tab_mode = 0;   // 0: the rule of geometry(), 1: score table always in LDS, 2: never (MDT_WAVE_TAB)
     int stop = 0;       // parameters end after phase k (0 = never; MDT_WAVE_STOP)
+    int osonly = 1;     // ess(kind = tail) alone ranks only the rounds that hold its quantiles (0: the full ranking; MDT_WAVE_OSONLY)
     unsigned* dbg = nullptr; // progress word per wave in host-pinned memory; honoured by -DWV_DEBUG / -DWV_PROF builds only (MDT_WAVE_DBG)
 };
 Geo geometry(long long n, long long niter, int f32, const Hooks& hk = Hooks(), int raw = 0); // raw: a raw-draw request (no score table)

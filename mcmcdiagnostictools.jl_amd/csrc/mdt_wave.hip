@@ -139,6 +139,7 @@ struct WvArgs {
     int perwave;           // bytes of LDS per wave (PERWAVE_SHORT or PERWAVE)
     unsigned* dbg;         // diagnostics (MDT_WAVE_DBG = address of a host-pinned array): progress word of every wave, or null
     int stop;              // diagnostics (MDT_WAVE_STOP behind the test-hooks gate): the parameter ends after phase `stop` with NaN outputs; 0 = never
+    int osonly;            // 1: ess(kind = tail) alone ranks only the rounds that hold its quantiles (MDT_WAVE_OSONLY=0: the full ranking; tests, A/B timing)
 };
 
 // What the phases of one parameter hand to each other: wave-uniform values in the wave's LDS block.  The phases are separate,
@@ -159,6 +160,8 @@ struct WS {
     unsigned lz, gw;                  // LDS address of the score table; global wave index
     unsigned tab_lds;                 // the score table of whole ranks sits in LDS (else: read from the global copy)
     unsigned view_bytes;              // bytes of the wave's block behind OFF_VIEW
+    unsigned osonly;                  // ess(kind = tail) alone: nothing but the two quantile pairs is wanted of the ranking (round 6) -- pass B stores
+                                      // only the classes of the rounds that hold them, only those rounds are ranked, the indicators come from x
 };
 static_assert(sizeof(WS) <= WS_BYTES, "wave state block");
 #define WV_LA __attribute__((address_space(3)))
@@ -493,6 +496,28 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
             vv[u] = (double)xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad];
         }
     };
+    // Order statistics only (ess(kind = tail) alone, round 6): the classes of the rounds that hold one of the four wanted places are
+    // marked (one byte per class, in the bytes of the moment tables, unused on this route); every member still draws its place -- the
+    // class cursors must end where the rounds expect them -- but only the marked classes are stored.
+    const bool osonly = rflu(ws->osonly) != 0u;
+    WV_LA unsigned char* wcl = (WV_LA unsigned char*)(wb + OFF_MEAN);
+    if (osonly) {
+        const WV_LA unsigned short* cst = (const WV_LA unsigned short*)(wb + OFF_CCUR); // (before pass B: the START of every class)
+        const WV_LA unsigned short* rtab = (const WV_LA unsigned short*)(wb + OFF_RTAB);
+        const unsigned nrounds = rflu(ws->nrounds), n_ = (unsigned)kp.n;
+        wcl[lane] = 0; wcl[64 + lane] = 0;
+        lds_fence();
+        if ((unsigned)lane < nrounds) {
+            const unsigned cA = rtab[lane], cB = rtab[lane + 1];
+            const unsigned g0 = cst[cA], g1 = cB < (unsigned)NCLS ? (unsigned)cst[cB] : n_;
+            const unsigned t4[4] = {(unsigned)(kp.q_j[0] - 1), (unsigned)kp.q_j[0], (unsigned)(kp.q_j[1] - 1), (unsigned)kp.q_j[1]};
+            bool tin = false;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tin = tin || (t4[t] >= g0 && t4[t] < g1);
+            if (tin) for (unsigned c = cA; c < cB; ++c) wcl[c] = 1;
+        }
+        lds_fence();
+    }
     double vn[UB];
     load_batch(0u, vn);
     for (unsigned r0 = 0; r0 < NRW; r0 += UB) {
@@ -506,13 +531,20 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
             cl[u] = clsb[ra_.eb + (ra_.d < D ? ra_.d : D - 1u)];
         }
         if (r0 + UB < NRW) load_batch(r0 + UB, vn);
+        if (osonly) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) cl[u] |= (unsigned)wcl[cl[u]] << 8; // (bit 8: the class is wanted)
+        }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const unsigned r = r0 + (unsigned)u;
             const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
             if (r < NRW && ra_.d < D) {
+                const bool keepit = !osonly || (cl[u] >> 8) != 0u;
+                cl[u] &= 0xFFu;
                 const unsigned shc = (cl[u] & 1u) << 4;
                 const unsigned pos = (lds_add(&ccur[cl[u] >> 1], 1u << shc) >> shc) & 0xFFFFu;
+                if (!keepit) continue;
                 unsigned k = 0u; // (s - 1 steps, usually one: kept from the loop vectoriser, which interleaved it by two behind a remainder loop)
 #pragma clang loop vectorize(disable) interleave(disable)
                 for (unsigned kk = 1u; kk < s; ++kk) k += (ra_.d >= row0(kk)) ? 1u : 0u;
@@ -547,7 +579,8 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     const unsigned nrounds = rflu(ws->nrounds);
     const bool need_med = kp.need_rt != 0;
     const bool need_q = kp.need_et && kp.ess_ok;
-    const bool need_ra = kp.need_eb || kp.need_rb || need_q; // ranks in time order: the z-series, and the tail indicators
+    const bool osonly = rflu(ws->osonly) != 0u; // (only the rounds that hold a wanted place are ranked; no rank list, no sorted copy)
+    const bool need_ra = (kp.need_eb || kp.need_rb || need_q) && !osonly; // ranks in time order: the z-series, and the tail indicators
     unsigned tp[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // 0-based places of the order statistics: median pair first, then the quantile pairs
     int ntgt = 0;
     {
@@ -585,8 +618,22 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             tg[i] = rc.t;
         }
     };
-    if (nrounds > 0u) issue(0u);
-    for (unsigned r = 0; r < nrounds; ++r) {
+    auto wanted_from = [&](unsigned r) -> unsigned { // the first round >= r that is ranked at all
+        if (!osonly) return r;
+        for (; r < nrounds; ++r) {
+            unsigned cA, cB, g0, g1;
+            round_span(r, cA, cB, g0, g1);
+            bool tin = false;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) tin = tin || (t < ntgt && tp[t] >= g0 && tp[t] < g1);
+            if (tin) break;
+        }
+        return r;
+    };
+    const unsigned rfirst = wanted_from(0u);
+    if (rfirst < nrounds) issue(rfirst);
+    for (unsigned r = rfirst; r < nrounds;) {
+        const unsigned rnext = wanted_from(r + 1u);
         unsigned cA, cB, g0, g1;
         round_span(r, cA, cB, g0, g1);
         const unsigned M = g1 - g0;
@@ -640,7 +687,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                 binid[pos] = (unsigned short)bn[i];
             }
         }
-        if (r + 1u < nrounds) issue(r + 1u);
+        if (rnext < nrounds) issue(rnext);
         lds_fence();
         WPROF(12);
         bool tin = false; // any target order statistic in this round?
@@ -703,11 +750,12 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                         rl[slot * niter + ps] = (r2 << 16) | ((tgv & 0xFFFFu) - (unsigned)jbase[slot]);
                     }
                 }
-                rec_store(rec + pos, x, (tgv >> 16) & 0xFFu);
+                if (!osonly) rec_store(rec + pos, x, (tgv >> 16) & 0xFFu);
             }
         }
         lds_fence();
         WPROF(13);
+        r = rnext;
     }
     anyodd = (__ballot(anyodd != 0u) != 0ull) ? 1u : 0u;
     mem_fence();
@@ -735,6 +783,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
                 if (pick < 0) zq_ok = 0;
                 else r2q[i] = orank[t + 2 * i + pick];
             }
+            if (osonly) zq_ok = 0; // (no rank was listed: the indicator phase compares x with the quantiles themselves)
         }
     }
     if (lane == 0) {
@@ -1444,6 +1493,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
             ws->p = p;
             ws->xp = (unsigned long long)((const T*)kp.x + p * kp.pstride);
             ws->fallback = 0; ws->zq_ok = 0; ws->bits_done = 0; ws->anyodd = 0u; ws->nrounds = 0u;
+            ws->osonly = (kp.need_et && kp.ess_ok && !kp.need_eb && !kp.need_rb && !kp.need_rt && wa.osonly) ? 1u : 0u;
             ws->out[0] = nan; ws->out[1] = nan; ws->out[2] = nan; ws->out[3] = nan;
         }
         lds_fence();
@@ -1579,6 +1629,7 @@ void launch(hipStream_t st, const KP* kp_slot, int f32, const Geo& g, int workgr
     wa.tab_bytes = g.tab_bytes;
     wa.perwave = g.perwave;
     wa.stop = hk.stop;
+    wa.osonly = hk.osonly;
 #if defined(WV_DEBUG) || defined(WV_PROF)
     wa.dbg = hk.dbg; // (diagnostics builds only: a release library never stores through a pointer that came from the environment)
 #else

@@ -1641,6 +1641,43 @@ def test_wave_path_matches_the_general_path(pkg, methods, monkeypatch):
     assert pkg.status() in (0, 2)
 
 
+def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, methods, monkeypatch):
+    """Round 6: ess(kind = tail) alone (src/ess_rhat.jl:301-311) needs nothing of the ranking but two pairs of order statistics: the
+    wave-per-parameter kernel then stores and ranks only the rounds that hold them and takes the indicators from x.  MDT_WAVE_OSONLY=0
+    ranks everything and takes the indicators from the ranks: the same bits (the indicator sums are exact integers), on continuous
+    data, heavy ties, Float32, every split; the general kernels (MDT_WAVE=0) and the oracle agree."""
+    import warnings
+    from oracle import c_oracle as co
+    rng = np.random.default_rng(707)
+    x = _wave_case_array(rng)
+    shapes = [("1000x4", x), ("997x4", x[:997]), ("250x4", x[:250]), ("f32", x.astype(np.float32)), ("1000x8", np.concatenate([x, x[::-1]], axis=1)),
+              ("ties", np.round(x, 1))]
+    for what, xs in shapes:
+        for s in (2, 1, 3):
+            D, C = xs.shape[:2]
+            if C * s > 16 or D // s > 1024 or D // s < 8 or D * C < 256 or D * C > 8192:
+                continue
+            xd = dev(xs)
+            outs = {}
+            for tag, env in (("only", {"MDT_WAVE": "2"}), ("full", {"MDT_WAVE": "2", "MDT_WAVE_OSONLY": "0"}), ("wg", {"MDT_WAVE": "0"})):
+                for k in ("MDT_WAVE", "MDT_WAVE_OSONLY"):
+                    monkeypatch.delenv(k, raising=False)
+                for k, v in env.items():
+                    monkeypatch.setenv(k, v)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    outs[tag] = [host(pkg.ess(xd, kind="tail", split_chains=s)), host(pkg.ess(xd, kind="tail", split_chains=s, tail_prob=0.3, maxlag=20, relative=True)),
+                                 host(pkg.ess(xd, kind="tail", split_chains=s, autocov_method=methods["fft"]))]
+            for k in ("MDT_WAVE", "MDT_WAVE_OSONLY"):
+                monkeypatch.delenv(k, raising=False)
+            for a, b, c in zip(outs["only"], outs["full"], outs["wg"]):
+                assert np.array_equal(a, b, equal_nan=True), (what, s)
+                assert_close(a, c, 1e-9 if xs.dtype == np.float64 else 2e-6, f"{what} s={s} against the general kernels")
+            if xs.dtype == np.float64:
+                e, _ = co.ess_rhat(xs, kind="tail", split_chains=s)
+                assert_close(outs["only"][0], e, RTOL64, f"{what} s={s} oracle")
+
+
 def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):
     """Round 6: raw draws -- ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) (src/ess_rhat.jl:438-603, src/mcse.jl:45-51) -- on
     short slices through the series phase of the wave-per-parameter kernel (no ranking).  Against the workgroup-per-parameter
