@@ -334,6 +334,20 @@ __device__ __forceinline__ RowAt row_at(unsigned r, unsigned rpc, unsigned D, lo
 }
 constexpr int UB = 8; // rows per batch of the streaming passes
 
+// 0-based sorted places of the order statistics a request wants captured: the median pair first (rhat(kind = tail)'s fold;
+// ess(kind = median), round 6), then the quantile pairs (ess(kind = tail): both; ess(kind = quantile(p)): the same pair twice)
+__device__ __forceinline__ int wv_targets(const WV_CA KP& kp, unsigned n, unsigned (&tp)[6], bool& need_med, bool& need_q) {
+    need_med = kp.need_rt != 0 || kp.est == 4;
+    need_q = (kp.need_et || kp.est == 7) && kp.ess_ok;
+#pragma unroll
+    for (int t = 0; t < 6; ++t) tp[t] = 0u;
+    const unsigned ql0 = (unsigned)(kp.q_j[0] - 1), ql1 = (unsigned)kp.q_j[0], qh0 = (unsigned)(kp.q_j[1] - 1), qh1 = (unsigned)kp.q_j[1];
+    if (need_med && need_q) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; tp[2] = ql0; tp[3] = ql1; tp[4] = qh0; tp[5] = qh1; return 6; }
+    if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; return 2; }
+    if (need_q) { tp[0] = ql0; tp[1] = ql1; tp[2] = qh0; tp[3] = qh1; return 4; }
+    return 0;
+}
+
 // ------------------------------------------------------------------ sample -> splitters; pass A: classes, histogram, range; rounds
 WV_PHASE void ph_classify(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
@@ -510,10 +524,12 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
         if ((unsigned)lane < nrounds) {
             const unsigned cA = rtab[lane], cB = rtab[lane + 1];
             const unsigned g0 = cst[cA], g1 = cB < (unsigned)NCLS ? (unsigned)cst[cB] : n_;
-            const unsigned t4[4] = {(unsigned)(kp.q_j[0] - 1), (unsigned)kp.q_j[0], (unsigned)(kp.q_j[1] - 1), (unsigned)kp.q_j[1]};
+            unsigned t6[6];
+            bool nm_, nq_;
+            const int nt_ = wv_targets(kp, n_, t6, nm_, nq_);
             bool tin = false;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) tin = tin || (t4[t] >= g0 && t4[t] < g1);
+            for (int t = 0; t < 6; ++t) tin = tin || (t < nt_ && t6[t] >= g0 && t6[t] < g1);
             if (tin) for (unsigned c = cA; c < cB; ++c) wcl[c] = 1;
         }
         lds_fence();
@@ -577,18 +593,11 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     WV_LA unsigned short* jbase = (WV_LA unsigned short*)(wb + OFF_JBASE);
     const unsigned n = (unsigned)kp.n, niter = (unsigned)kp.niter;
     const unsigned nrounds = rflu(ws->nrounds);
-    const bool need_med = kp.need_rt != 0;
-    const bool need_q = kp.need_et && kp.ess_ok;
+    bool need_med, need_q;
+    unsigned tp[6]; // 0-based places of the order statistics: median pair first, then the quantile pairs
+    const int ntgt = wv_targets(kp, n, tp, need_med, need_q);
     const bool osonly = rflu(ws->osonly) != 0u; // (only the rounds that hold a wanted place are ranked; no rank list, no sorted copy)
     const bool need_ra = (kp.need_eb || kp.need_rb || need_q) && !osonly; // ranks in time order: the z-series, and the tail indicators
-    unsigned tp[6] = {0u, 0u, 0u, 0u, 0u, 0u}; // 0-based places of the order statistics: median pair first, then the quantile pairs
-    int ntgt = 0;
-    {
-        const unsigned ql0 = (unsigned)(kp.q_j[0] - 1), ql1 = (unsigned)kp.q_j[0], qh0 = (unsigned)(kp.q_j[1] - 1), qh1 = (unsigned)kp.q_j[1];
-        if (need_med && need_q) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; tp[2] = ql0; tp[3] = ql1; tp[4] = qh0; tp[5] = qh1; ntgt = 6; }
-        else if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; ntgt = 2; }
-        else if (need_q) { tp[0] = ql0; tp[1] = ql1; tp[2] = qh0; tp[3] = qh1; ntgt = 4; }
-    }
     if (lane < WV_MAXM) { // per split chain: fill of its rank list; pooled index of its first draw (src/utils.jl:29-36)
         const unsigned s_ = (unsigned)kp.s, rem_ = (unsigned)kp.rem, c = (unsigned)lane / s_, k = (unsigned)lane - c * s_;
         lcur[lane] = 0u;
@@ -786,6 +795,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             if (osonly) zq_ok = 0; // (no rank was listed: the indicator phase compares x with the quantiles themselves)
         }
     }
+    if (kp.est == 4) { qq[0] = medT; qq[1] = medT; zq_ok = 0; } // ess(kind = median): the indicator of x <= median (src/ess_rhat.jl:630-633), both thresholds the same
     if (lane == 0) {
         ws->anyodd = anyodd; ws->med = (double)medT; ws->qlo = (double)qq[0]; ws->qhi = (double)qq[1];
         ws->zq_ok = zq_ok; ws->r2q[0] = r2q[0]; ws->r2q[1] = r2q[1];
@@ -1493,7 +1503,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
             ws->p = p;
             ws->xp = (unsigned long long)((const T*)kp.x + p * kp.pstride);
             ws->fallback = 0; ws->zq_ok = 0; ws->bits_done = 0; ws->anyodd = 0u; ws->nrounds = 0u;
-            ws->osonly = (kp.need_et && kp.ess_ok && !kp.need_eb && !kp.need_rb && !kp.need_rt && wa.osonly) ? 1u : 0u;
+            ws->osonly = ((kp.need_et || kp.est) && kp.ess_ok && !kp.need_eb && !kp.need_rb && !kp.need_rt && wa.osonly) ? 1u : 0u;
             ws->out[0] = nan; ws->out[1] = nan; ws->out[2] = nan; ws->out[3] = nan;
         }
         lds_fence();
@@ -1553,7 +1563,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
                             else ph_series<T, (WV_NITER + 63) / 64>(wbase);
                         }
                         WDBG(60);
-                        if (kp.need_et && kp.ess_ok && stop != 5) {
+                        if ((kp.need_et || kp.est) && kp.ess_ok && stop != 5) {
                             if (nblk <= 4u) ph_indicators<T, 4>(wbase);
                             else if (nblk <= 8u) ph_indicators<T, 8>(wbase);
                             else if (nblk <= (unsigned)((WV_NITER_SHORT + 63) / 64)) ph_indicators<T, (WV_NITER_SHORT + 63) / 64>(wbase);
@@ -1566,6 +1576,8 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         WDBG(70);
         if (fb) { // the general kernel, queued behind this launch, serves the parameter
             if (lane == 0) { const int i = atomicAdd(wa.fb_count, 1); wa.fb_list[i] = (unsigned)p; }
+        } else if (kp.est) { // ess(kind = median | quantile(p)): the ESS of the one indicator (the two "tails" are the same series)
+            if (lane == 0) store_out<T>(kp.out_eb, p, ws->out[2]);
         } else if (lane == 0) {
             const double eb_ = ws->out[0], rb_ = ws->out[1], et_ = ws->out[2], rt_ = ws->out[3];
             store_out<T>(kp.out_eb, p, eb_);

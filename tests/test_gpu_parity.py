@@ -332,11 +332,16 @@ def test_both_rank_variants_agree_bitwise(pkg, monkeypatch):
                 assert np.array_equal(a, b, equal_nan=True), (v, k)
 
 
+@pytest.mark.parametrize("wave_forced", [False, True], ids=["rule", "wave"])
 @pytest.mark.parametrize("name", golden_names(estimators=True))
-def test_estimator_kinds(pkg, methods, name):
+def test_estimator_kinds(pkg, methods, name, monkeypatch, wave_forced):
     """ess(x; kind = estimator) for the estimators with an expectand proxy and mcse(kind = std) against the
-    golden vectors"""
+    golden vectors; wave_forced: the same through the wave-per-parameter kernel wherever it can run
+    (round 6: ess(kind = median | quantile(p)) on short slices -- the order-statistics-only ranking and the indicator phase of
+    ess(kind = tail); everything else takes the general kernels as always)"""
     import warnings
+    if wave_forced:
+        monkeypatch.setenv("MDT_WAVE", "2")
     g = load_golden(name)
     x = load_golden(name[4:])["x"]
     xd = dev(x)
@@ -1667,7 +1672,8 @@ def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, me
                 with warnings.catch_warnings():
                     warnings.simplefilter("ignore")
                     outs[tag] = [host(pkg.ess(xd, kind="tail", split_chains=s)), host(pkg.ess(xd, kind="tail", split_chains=s, tail_prob=0.3, maxlag=20, relative=True)),
-                                 host(pkg.ess(xd, kind="tail", split_chains=s, autocov_method=methods["fft"]))]
+                                 host(pkg.ess(xd, kind="tail", split_chains=s, autocov_method=methods["fft"])),
+                                 host(pkg.ess(xd, kind=np.median, split_chains=s)), host(pkg.ess(xd, kind=pkg.Quantile(0.37), split_chains=s, maxlag=60))]
             for k in ("MDT_WAVE", "MDT_WAVE_OSONLY"):
                 monkeypatch.delenv(k, raising=False)
             for a, b, c in zip(outs["only"], outs["full"], outs["wg"]):
@@ -1676,6 +1682,7 @@ def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, me
             if xs.dtype == np.float64:
                 e, _ = co.ess_rhat(xs, kind="tail", split_chains=s)
                 assert_close(outs["only"][0], e, RTOL64, f"{what} s={s} oracle")
+                assert_close(outs["only"][3], co.ess_estimator(xs, "median", split_chains=s), RTOL64, f"{what} s={s} oracle median")
 
 
 def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):
