@@ -352,6 +352,76 @@ def other_configs(pkg, device, steps, warmup):
     return out
 
 
+def request_kinds(pkg, device, steps=3):
+    """Partial requests -- what the reference's API hands out one call at a time (`ess(kind = :tail)`, `rhat(kind = :tail)`,
+    `mcse(kind = mean)`, `kind = :basic`, `ess(kind = median)`) -- on config 1's slice shape at scale and on config 2's: time per
+    call on the default path and, beside it, on the path that served the request until round 5 (the library's own switch, behind
+    the test-hooks gate the bench sets): round 6 stopped such requests from paying for pipeline stages they do not need."""
+    import warnings
+    from oracle import c_oracle
+    out = {"note": "ms per call (HIP events, synchronous API calls), 3 timed calls after one warm-up; `before` = the same request on the "
+                   "route of rounds 1-5 (MDT_WAVE=0: workgroup-per-parameter kernels; MDT_WAVE_OSONLY=0: full ranking on the wave kernel; "
+                   "MDT_TAIL_SRT=0: order-statistics-only ranking + a second full ranking of |x - median|)"}
+
+    def both(fn, env):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            now = timed_ms(fn, steps, 1)
+            old = dict((k, os.environ.get(k)) for k in env)
+            os.environ.update(env)
+            try:
+                before = timed_ms(fn, steps, 1)
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return {"ms": round(now, 3), "ms_before": round(before, 3)}
+
+    # config 1's slice shape at scale: the wave-per-parameter kernel
+    D, C, P = 1_000, 4, 100_000
+    x_pcd = synth(D, C, P, device, seed=1234, chunk=10_000)
+    x = x_pcd.permute(2, 1, 0)
+    rows = {}
+    rows["rhat_basic"] = both(lambda: pkg.rhat(x, kind="basic"), {"MDT_WAVE": "0"})
+    rows["ess_rhat_basic"] = both(lambda: pkg.ess_rhat(x, kind="basic"), {"MDT_WAVE": "0"})
+    rows["mcse_mean"] = both(lambda: pkg.mcse(x), {"MDT_WAVE": "0"})
+    rows["ess_tail"] = both(lambda: pkg.ess(x, kind="tail"), {"MDT_WAVE_OSONLY": "0"})
+    rows["ess_median"] = both(lambda: pkg.ess(x, kind=np.median), {"MDT_WAVE": "0"})
+    pick = np.array([0, 5, P // 2 + 6, P - 1])
+    xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = [pkg.mcse(x).cpu().numpy()[pick], pkg.ess(x, kind="tail").cpu().numpy()[pick], pkg.rhat(x, kind="basic").cpu().numpy()[pick]]
+    want = [c_oracle.mcse_mean(xs), c_oracle.ess_rhat(xs, kind="tail")[0], c_oracle.ess_rhat(xs, kind="basic")[1]]
+    out["config1_shape"] = {"workload": f"{D} draws x {C} chains x {P} params Float64", "rows": rows,
+                            "parity_max_rel_err_vs_oracle": max_rel_err(got, want),
+                            "parity_sample": f"mcse(mean), ess(tail), rhat(basic) of {len(pick)} parameters against oracle/mdt_oracle.c"}
+    del x, x_pcd
+    torch.cuda.empty_cache()
+    # config 2's shape: the workgroup-per-parameter kernels
+    D, C, P = 10_000, 4, 10_000
+    x_pcd = synth(D, C, P, device, seed=1234)
+    x = x_pcd.permute(2, 1, 0)
+    rows = {}
+    rows["ess_rhat_tail"] = both(lambda: pkg.ess_rhat(x, kind="tail"), {"MDT_TAIL_SRT": "0"})
+    rows["rhat_tail"] = both(lambda: pkg.rhat(x, kind="tail"), {"MDT_TAIL_SRT": "0"})
+    pick = np.array([1, P // 2 + 3, P - 1])
+    xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        e, r = pkg.ess_rhat(x, kind="tail")
+    we, wr = c_oracle.ess_rhat(xs, kind="tail")
+    out["config2_shape"] = {"workload": f"{D} draws x {C} chains x {P} params Float64", "rows": rows,
+                            "parity_max_rel_err_vs_oracle": max_rel_err([e.cpu().numpy()[pick], r.cpu().numpy()[pick]], [we, wr]),
+                            "parity_sample": f"ess_rhat(kind = tail) of {len(pick)} parameters against oracle/mdt_oracle.c"}
+    out["status_flags"] = pkg.status()
+    del x, x_pcd
+    torch.cuda.empty_cache()
+    return out
+
+
 def wave_rule(D, C, P, split=2):
     """the host's dispatch rule for the wave-per-parameter kernel (run() in csrc/mdt_hip.hip): slices of 256 ... 8192
     values in at most 16 split chains of 8 ... 1024 draws, from the parameter count at which a wave per parameter pays"""
@@ -725,6 +795,7 @@ def main():
         torch.cuda.empty_cache()
         res["other_configs"] = other_configs(pkg, device, steps=5, warmup=1)
         res["other_configs"]["shape_sweep"] = shape_sweep(pkg, device)
+        res["other_configs"]["request_kinds"] = request_kinds(pkg, device)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

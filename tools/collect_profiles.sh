@@ -5,7 +5,7 @@
 # workloads (separate passes per counter group), phase tables.
 # usage (inside gpurun): bash tools/collect_profiles.sh <tag>      then, back home: python tools/summarize_profiles.py <tag>
 # (gpurun merges the box's gpurun_out/<tag> into the local one: `rm -rf gpurun_out/<tag>` first, or files of an earlier collection stay beside the new ones)
-R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r05}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-r06}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R && python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 python tools/phase_profile.py --params 10000 > $O/phase_cfg2.txt 2>/dev/null
@@ -23,6 +23,7 @@ for sh in "1000 4" "500 4" "250 4" "1000 8"; do for P in 1000 2000 4000 8000 160
   echo -n "MDT_WAVE=$w "; MDT_TEST_HOOKS=1 MDT_WAVE=$w python tools/time_shape.py $sh $P 2>/dev/null | tail -1 | cut -c1-48; done; done; done > $O/wave_crossover.txt
 python tools/time_strided.py > $O/strided.txt 2>/dev/null
 python tools/time_kinds.py > $O/kinds.txt 2>/dev/null
+python tools/time_kinds.py 100000 1000 4 > $O/kinds_1000x4.txt 2>/dev/null   # (round 6: partial requests on config 1's slice shape)
 cd /tmp && export TMPDIR=/tmp
 # the program itself directly behind `--` (no env / bash -c hop: the profiler's preload initialises the GPU first)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_under_rocprof.json 2>/dev/null

@@ -16,7 +16,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join("gpurun_out", tag)
 os.makedirs("profiles", exist_ok=True)
 for name in ("bench.json", "bench_under_rocprof.json"):
@@ -62,7 +62,7 @@ if tr:
                 t = d[w0:w0 + under["steps"]]
                 fo.write(f"  headline's timed steps (dispatches {w0 + 1}..{w0 + len(t)} of this kernel and grid): mean {sum(t) / len(t):.3f} ms\n")
 
-for name in ("phase_cfg2", "phase_cfg3", "phase_cfg5_rank", "cfg5_split", "wave_crossover", "phase_wave_1000x4", "phase_wave_500x4", "strided", "kinds"):
+for name in ("phase_cfg2", "phase_cfg3", "phase_cfg5_rank", "cfg5_split", "wave_crossover", "phase_wave_1000x4", "phase_wave_500x4", "strided", "kinds", "kinds_1000x4"):
     p = os.path.join(src, name + ".txt")
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, f"profiles/{tag}_{name}.txt")
