@@ -677,13 +677,15 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     // Round 6: raw draws too -- ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) (no row dropped by the split: its pooled
     // standard deviation then follows from the split-chain moments) -- through the series phase of the same kernel, no ranking, no
     // per-wave scratch.  R-hat is the same bits as on the workgroup-per-parameter kernels (the same summation order).
-    const bool wave_raw = rq.basic && rq.est == 0 && (rq.mode == 0 || (rq.mode == 2 && D % s == 0)) && (rq.need_eb || rq.need_rb);
-    const bool wave_pays = wave_raw ? wave_raw_pays(n, P, rq.need_eb && ess_ok) : wave_shape_pays(n, niter, P);
+    // ... and the std proxy (x - mean)^2: ess(kind = std) and mcse(kind = std) (src/ess_rhat.jl:640-642, src/mcse.jl:52-65)
+    const bool wave_std = rq.basic && rq.est == MDT_KIND_STD && (rq.mode == 0 || rq.mode == 4) && ess_ok;
+    const bool wave_raw = wave_std || (rq.basic && rq.est == 0 && (rq.mode == 0 || (rq.mode == 2 && D % s == 0)) && (rq.need_eb || rq.need_rb));
+    const bool wave_pays = wave_raw ? wave_raw_pays(n, P, (rq.need_eb || wave_std) && ess_ok) : wave_shape_pays(n, niter, P);
     // ... and the indicator estimators whose threshold is an order statistic of x itself: ess(kind = median | quantile(p))
     // (src/ess_rhat.jl:630-633, 647-659) -- the order-statistics-only ranking and the indicator phase of ess(kind = tail)
     const bool wave_est = (rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_QUANTILE) && rq.mode == 0 && !rq.basic && ess_ok;
-    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && ((rq.mode == 0 && !rq.basic) || wave_raw) && (rq.est == 0 || wave_est) &&
-                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt || wave_est) && wave_shape_fits(n, niter, m) &&
+    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && ((rq.mode == 0 && !rq.basic) || wave_raw) && (rq.est == 0 || wave_est || wave_std) &&
+                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt || wave_est || wave_std) && wave_shape_fits(n, niter, m) &&
                       maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&
                       !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2) && P < 0x7FFFFFFFLL;
 

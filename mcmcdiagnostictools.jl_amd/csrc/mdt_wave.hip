@@ -1005,6 +1005,51 @@ WV_PHASE void ph_fold(unsigned wbase_arg) {
     WPROF(6);
 }
 
+// ------------------------------------------------------------------ the std proxy: pooled mean, pooled moments of (x - mean)^2
+// ess(kind = std) / mcse(kind = std) (src/ess_rhat.jl:640-642, src/mcse.jl:52-65; round 6): the expectand proxy (x - mean(x))^2, evaluated
+// in T like SerSq of mdt_device.hpp, needs the mean over ALL draws of the slice first (rows the split drops included), mcse(std) also
+// the pooled mean of the proxy and of its square.  Two streaming sweeps over the slice (the second one finds it in the cache).
+WV_PHASE void ph_pooled_sq(unsigned wbase_arg) {
+    WV_ENTER(wbase_arg);
+    const WV_GA T* xp = (const WV_GA T*)rfl64(ws->xp);
+    const unsigned D = (unsigned)kp.D, C = (unsigned)kp.C;
+    const long long cs = kp.cstride;
+    const unsigned rpc = (D + 63u) >> 6, NRW = C * rpc;
+    const double dn = (double)kp.n;
+    double acc = 0.0;
+    for (unsigned r0 = 0; r0 < NRW; r0 += UB) {
+        double vv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const unsigned r = r0 + (unsigned)u;
+            const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
+            vv[u] = (r < NRW && ra_.d < D) ? (double)xp[ra_.ad] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc += vv[u];
+    }
+    const T muT = (T)(wave_sum_d(acc) / dn);
+    double l1 = 0.0, l2 = 0.0;
+    if (kp.mode == 4) {
+        for (unsigned r0 = 0; r0 < NRW; r0 += UB) {
+            double yy[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const unsigned r = r0 + (unsigned)u;
+                const RowAt ra_ = row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane);
+                const T d = (T)(xp[ra_.ad] - muT);
+                yy[u] = (r < NRW && ra_.d < D) ? (double)(T)(d * d) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) { l1 += yy[u]; l2 = fma(yy[u], yy[u], l2); }
+        }
+        l1 = wave_sum_d(l1) / dn;
+        l2 = wave_sum_d(l2) / dn;
+    }
+    if (lane == 0) { ws->med = (double)muT; ws->qlo = l1; ws->qhi = l2; } // (the order-statistic fields: unused by raw requests)
+    lds_fence();
+}
+
 // ------------------------------------------------------------------ bulk series: moments, lag products, Geyer's scan
 // Per split chain: doubled ranks (time order) -> scores (the workgroup's LDS table) -> stage in LDS, shifted by the score of
 // the chain's first draw; exact fixed-point moments (the integers and expressions of series_z_phase, mdt_series.inc: R-hat is
@@ -1036,7 +1081,9 @@ template <typename T, int NB, bool RAW = false> __device__ __attribute__((noinli
     const long long maxlag = kp.maxlag;
     const double nan = __builtin_nan(""), dn = (double)niter, dm = (double)m;
     const Fx fx = Fx::make(kp.niter);
-    const bool acov = kp.need_eb && kp.ess_ok;
+    const bool acov = (kp.need_eb || (RAW && kp.est == 5)) && kp.ess_ok;
+    const bool sq = RAW && kp.est == 5;              // the std proxy (x - mean)^2 in T, mean from ph_pooled_sq
+    const T muT = (T)rfld(ws->med);
     const bool anyodd = rflu(ws->anyodd) != 0u;
     const unsigned nblk = (niter + 63u) >> 6;
     const int c_hi = 16 * ((int)maxlag / 16 + 1);
@@ -1100,6 +1147,10 @@ template <typename T, int NB, bool RAW = false> __device__ __attribute__((noinli
             if constexpr (RAW) {
 #pragma unroll
                 for (int b = 0; b < NB; ++b) z[b] = (double)xn[b];
+                if (sq) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) { const T d = (T)(xn[b] - muT); z[b] = (double)(T)(d * d); }
+                }
                 if (j + 1 < m) issue(j + 1);
             } else {
 #pragma unroll
@@ -1513,6 +1564,7 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         if (kp.basic) {
             // raw draws (round 6): ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) -- no ranking, the series phase alone
             const unsigned nblk = ((unsigned)kp.niter + 63u) >> 6;
+            if (kp.est == 5) ph_pooled_sq<T>(wbase);
             if (nblk <= 4u) ph_series<T, 4, true>(wbase);
             else if (nblk <= 8u) ph_series<T, 8, true>(wbase);
             else if (nblk <= (unsigned)((WV_NITER_SHORT + 63) / 64)) ph_series<T, (WV_NITER_SHORT + 63) / 64, true>(wbase);
@@ -1520,8 +1572,12 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
             if (rfl(ws->fallback) != 0) {
                 if (lane == 0) { const int i = atomicAdd(wa.fb_count, 1); wa.fb_list[i] = (unsigned)p; }
             } else if (lane == 0) {
-                const double ess = (kp.need_eb && kp.ess_ok) ? ws->out[0] : nan;
-                if (kp.mode == 2) {
+                const double ess = ((kp.need_eb || kp.est == 5) && kp.ess_ok) ? ws->out[0] : nan;
+                if (kp.est == 5) {
+                    // ess(kind = std): the basic ESS of the proxy; mcse(kind = std) = sqrt((E[mu4] / E[var] - E[var]) / S) / 2 (src/mcse.jl:52-65)
+                    const double mv = ws->qlo, m4 = ws->qhi;
+                    store_out<T>(kp.out_eb, p, kp.mode == 4 ? sqrt((m4 / mv - mv) / ess) / 2.0 : ess);
+                } else if (kp.mode == 2) {
                     // mcse(kind = mean) = pooled corrected std / sqrt(ESS) (src/mcse.jl:45-51); every draw belongs to a split chain here
                     // (no row dropped by the split), so the pooled moments follow from the split-chain ones -- Chan's combination, the
                     // expressions of raw_request in mdt_device.hpp

@@ -1711,6 +1711,8 @@ def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):
             out.append(("ess only rel", host(pkg.ess(xd, kind="basic", split_chains=s, relative=True, maxlag=30))))
             out.append(("ess fft", host(pkg.ess(xd, kind="basic", split_chains=s, autocov_method=methods["fft"]))))
             out.append(("mcse", host(pkg.mcse(xd, split_chains=s))))
+            out.append(("std ess", host(pkg.ess(xd, kind=np.std, split_chains=s))))        # the proxy (x - mean)^2 (src/ess_rhat.jl:640-642)
+            out.append(("std mcse", host(pkg.mcse(xd, kind=np.std, split_chains=s))))      # src/mcse.jl:52-65
         return out
 
     for what, xs in shapes:
@@ -1727,9 +1729,13 @@ def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):
             for (ka, va), (kb, vb) in zip(a, b):
                 if "rhat" in ka:
                     assert np.array_equal(va, vb, equal_nan=True), (what, s, ka, va, vb)
+                elif ka.startswith("std"):  # (the pooled mean of the proxy is a thread-strided sum on the workgroup kernels: another order here)
+                    assert_close(va, vb, 1e-9 if xs.dtype == np.float64 else 5e-5, f"{what} s={s} {ka}")
                 else:
                     assert_close(va, vb, 1e-12 if xs.dtype == np.float64 else 2e-6, f"{what} s={s} {ka}")
             if xs.dtype == np.float64:
+                assert_close(a[6][1], co.ess_estimator(xs, "std", split_chains=s), RTOL64, f"{what} s={s} oracle ess std")
+                assert_close(a[7][1], co.mcse_std(xs, split_chains=s), RTOL64, f"{what} s={s} oracle mcse std")
                 e, r = co.ess_rhat(xs, kind="basic", split_chains=s)
                 assert_close(a[0][1], e, RTOL64, f"{what} s={s} oracle ess")
                 assert_close(a[1][1], r, RTOL64, f"{what} s={s} oracle rhat")

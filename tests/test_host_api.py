@@ -109,3 +109,17 @@ def test_library_beta_inverse_against_scipy(pkg):
             worst_fwd = max(worst_fwd, abs(out.value / betainc(a, b, xs) - 1))
     assert worst_inv < 2e-10 and worst_fwd < 2e-10, (worst_inv, worst_fwd)
     assert lib.mdt_debug_beta(-1.0, 2.0, 0.5, 1, ctypes.byref(out)) == 1  # MDT_EARG
+
+
+def test_describe_finds_what_prepare_finds_without_copying(pkg):
+    """reserve(like = array) (round 6): shape, eltype, location and context key of the request the array would make -- the rule of
+    _prepare / _ctx_key -- without the dense copy _prepare takes of a host array"""
+    api = pkg.api
+    for x in (np.zeros((100, 4, 7), dtype=np.float32), np.zeros((50, 3)), np.zeros(40), np.zeros((20, 2, 3, 5)), np.zeros((30, 2, 4), dtype=np.int64)):
+        d, pr = api._describe(x), api._prepare(x)
+        assert (d.D, d.C, d.P, d.f32, d.dev) == (pr.D, pr.C, pr.P, pr.f32, pr.dev), x.shape
+        assert api._ctx_key(d) == api._ctx_key(pr) == (0, 0)   # a host request runs on the context of (device 0, stream 0)
+        a = api._args(d, 0, 0, 0, 2, 250, False, 0.1)
+        assert (a.draws, a.chains, a.params, a.location, a.chain_stride, a.param_stride) == (pr.D, pr.C, pr.P, pkg._lib.MDT_HOST, 0, 0)
+    with pytest.raises(pkg.ArgumentError):
+        api._describe(np.float64(1.0))

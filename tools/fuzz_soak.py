@@ -140,6 +140,9 @@ while time.time() - t0 < budget:
         for est, kind in (("median", np.median), ("mad", "mad")):
             got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             check(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), tol, what + " " + est, True, short)  # (an indicator series is discrete whatever x is)
+        if D // s > 4 and not f32 and fl != "offset":  # the std proxy (x - mean)^2: ess(kind = std), mcse(kind = std) (round 6: on the wave kernel too)
+            check(host(pkg.ess(xd, kind=np.std, autocov_method=methods[m], split_chains=s, maxlag=ml)), co.ess_estimator(x, "std", autocov=m, split_chains=s, maxlag=ml), tol, what + " ess std", disc, short)
+            check(host(pkg.mcse(xd, kind=np.std, autocov_method=methods[m], split_chains=s, maxlag=ml)), co.mcse_std(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse std", disc, short)
         if D // s > 4:  # mcse(kind = mean): raw draws (round 6: on short slices through the wave-per-parameter kernel too)
             check(host(pkg.mcse(xd, split_chains=s, maxlag=ml, autocov_method=methods[m])), co.mcse_mean(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse mean", disc, short)
         if C * s >= 2 and C % 2 == 0 and C >= 4:
