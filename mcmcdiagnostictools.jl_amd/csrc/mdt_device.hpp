@@ -631,7 +631,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
             for (long long e = tid; e < n; e += NT) loc += (double)xp[e];
             const T muT = (T)(wg_sum(loc, red) / (double)n);
             const SerSq<T> YS{(const MDT_GA T*)xp, D, muT};
-            const SeriesOut so = many ? many_phase(kp, YS, xs, kp.ess_ok != 0, smem) : basic_ess_rhat(YS, kp.ess_ok != 0);
+            // (round 6: a split chain that fits the LDS takes the one-chain-per-buffer sweep of the raw draws with the proxy applied on
+            // the fly -- moments and lag products from one staged pass -- instead of the tiled series_phase)
+            SeriesOut so;
+            if (many) so = many_phase(kp, YS, xs, kp.ess_ok != 0, smem);
+            else if (zfast && !fft_lds && kp.ess_ok && kp.sq_fast) {
+                so = series_z_phase<false, true, T, true>(kp, xp, nullptr, true, smem, nullptr, 0.0, 0.0, true, (double)muT);
+                so.ess = fft_const_chain_nan(so.ess);
+            } else so = basic_ess_rhat(YS, kp.ess_ok != 0);
             const double ess = kp.ess_ok ? so.ess : nan;
             if (kp.mode == 4) {
                 // src/mcse.jl:52-65: sqrt((E[mu4] / E[var] - E[var]) / S) / 2, E[var] = mean(proxy), E[mu4] = mean(proxy^2)
