@@ -112,6 +112,7 @@ struct mdt_ctx {
     int force_cfg = 0; // MDT_CONFIG=big|small|tiny (tests, A/B timing): 1 big, 2 small, 3 tiny, 0 automatic
     std::string err;
     // per-workgroup scratch
+    void* scratch_slab = nullptr; // ONE allocation behind the five per-workgroup scratch arrays below (round 6: five hipMalloc calls were ~8 ms of a first call)
     unsigned int* r2buf = nullptr;
     double* zbuf = nullptr;
     double* xsbuf = nullptr;
@@ -467,17 +468,19 @@ int ensure_scratch(mdt_ctx* ctx, long long n, long long wgs) {
     const long long need = wgs * n_pad;
     if (need > ctx->scratch_elems) {
         if (ctx->used) HIP_TRY(hipStreamSynchronize(ctx->last_stream)); // launches still queued work in the old buffers
-        if (ctx->r2buf) (void)hipFree(ctx->r2buf);
-        if (ctx->binbuf) (void)hipFree(ctx->binbuf);
-        if (ctx->zbuf) (void)hipFree(ctx->zbuf);
-        if (ctx->xsbuf) (void)hipFree(ctx->xsbuf);
-        if (ctx->bsbuf) (void)hipFree(ctx->bsbuf);
+        if (ctx->scratch_slab) (void)hipFree(ctx->scratch_slab);
+        ctx->scratch_slab = nullptr;
         ctx->r2buf = nullptr; ctx->binbuf = nullptr; ctx->zbuf = nullptr; ctx->xsbuf = nullptr; ctx->bsbuf = nullptr; ctx->scratch_elems = 0;
-        HIP_TRY(hipMalloc((void**)&ctx->r2buf, (size_t)need * sizeof(unsigned int)));
-        HIP_TRY(hipMalloc((void**)&ctx->binbuf, (size_t)need * sizeof(unsigned short)));
-        HIP_TRY(hipMalloc((void**)&ctx->zbuf, (size_t)need * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&ctx->xsbuf, (size_t)need * sizeof(double)));
-        HIP_TRY(hipMalloc((void**)&ctx->bsbuf, (size_t)need * sizeof(unsigned short)));
+        // one slab, the arrays at 256-byte boundaries inside it (widest element type first)
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t bz = up((size_t)need * sizeof(double)), br = up((size_t)need * sizeof(unsigned int)), bb = up((size_t)need * sizeof(unsigned short));
+        HIP_TRY(hipMalloc(&ctx->scratch_slab, 2 * bz + br + 2 * bb));
+        char* base = (char*)ctx->scratch_slab;
+        ctx->zbuf = (double*)base;
+        ctx->xsbuf = (double*)(base + bz);
+        ctx->r2buf = (unsigned int*)(base + 2 * bz);
+        ctx->binbuf = (unsigned short*)(base + 2 * bz + br);
+        ctx->bsbuf = (unsigned short*)(base + 2 * bz + br + bb);
         ctx->scratch_elems = need;
     }
     ctx->n_pad = n_pad; // the stride of this request: every workgroup owns [blockIdx * n_pad, +n_pad)
@@ -1269,11 +1272,7 @@ int mdt_ctx_destroy(mdt_ctx* ctx) {
     }
     DeviceGuard guard(ctx->device);
     (void)hipDeviceSynchronize();
-    if (ctx->r2buf) (void)hipFree(ctx->r2buf);
-    if (ctx->binbuf) (void)hipFree(ctx->binbuf);
-    if (ctx->zbuf) (void)hipFree(ctx->zbuf);
-    if (ctx->xsbuf) (void)hipFree(ctx->xsbuf);
-    if (ctx->bsbuf) (void)hipFree(ctx->bsbuf);
+    if (ctx->scratch_slab) (void)hipFree(ctx->scratch_slab);
     if (ctx->ztab) (void)hipFree(ctx->ztab);
     if (ctx->status) (void)hipFree(ctx->status);
     if (ctx->prof) (void)hipFree(ctx->prof);
