@@ -582,6 +582,17 @@ def test_tail_only_request_takes_the_merge_and_changes_no_bit(pkg, monkeypatch):
         for a, b in zip(outs["1"], outs["0"]):
             assert np.array_equal(a, b, equal_nan=True), what
         assert np.array_equal(outs["1"][1], outs["1"][2], equal_nan=True), what + ": rhat(tail) == ess_rhat(tail).rhat"
+        if x.shape[1] % 2 == 0 and x.shape[1] >= 4:  # rhat_nested(kind = tail) takes the same route (src/rhat_nested.jl:118-124)
+            C = x.shape[1]
+            ids = np.repeat(np.arange(C // 2), 2)
+            nest = {}
+            for sw in ("1", "0"):
+                monkeypatch.setenv("MDT_TAIL_SRT", sw)
+                nest[sw] = host(pkg.rhat_nested(xd, ids, kind="tail"))
+            monkeypatch.delenv("MDT_TAIL_SRT", raising=False)
+            assert np.array_equal(nest["1"], nest["0"], equal_nan=True), what + ": nested R-hat of the folded draws"
+            inds = np.arange(C, dtype=np.int32).reshape(C // 2, 2).T.copy()
+            assert_close(nest["1"], co.rhat_nested(np.asarray(x, dtype=np.float64), inds, kind="tail"), RTOL64 if x.dtype == np.float64 else 1e-6, what + ": nested tail against the oracle")
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             fused = [host(o) for o in pkg.bulk_tail(xd)]
