@@ -853,6 +853,7 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     { const char* pe = hook("MDT_PA"); kp.pa_on = pe ? atoi(pe) : 1; }
     { const char* te = hook("MDT_TAIL_SRT"); kp.tail_srt = te ? atoi(te) : 1; }
     { const char* qe = hook("MDT_SQ_FAST"); kp.sq_fast = qe ? atoi(qe) : 1; }
+    { const char* fe = hook("MDT_F4_STAG"); kp.f4_stag = fe ? atoi(fe) : 3; } // bit 0: slots of the sorted copy, bit 1: moments in sorted order
     kp.onechunk = onechunk ? 1 : 0;
     kp.out_eb = outs_dev[0]; kp.out_rb = outs_dev[1]; kp.out_et = outs_dev[2]; kp.out_rt = outs_dev[3];
     kp.out_rrank = outs_dev[4];

@@ -29,6 +29,7 @@ struct KP {
     int pa_on;                  // 1: tile-major partition where it applies (rank_phase_q, `pa`); 0: histogram + partition passes (MDT_PA=0: tests, A/B timing)
     int rank_variant;           // 0: rounds re-stream the slice (rank_phase_b), 1: partitioned rounds (rank_phase_p), 2: two-level (rank_phase_q)
     int tail_srt;               // 1: a tail-only request with R-hat ranks every round for the sorted copy, its folded ranking is the merge (round 6); 0: order statistics only + the general folded ranking (MDT_TAIL_SRT=0: tests, A/B timing)
+    int f4_stag;                // Float32 rounds keep the split-chain slot of every chunk slot in a byte array behind the chunk (round 6): bit 0 the slots of the sorted copy leave from there (0: the three-barrier route), bit 1 a moments-only round adds its scores to the chains' sums in sorted order (0: back to partition order first); MDT_F4_STAG=0..3: tests, A/B timing
     int sq_fast;                // 1: the std proxy takes the one-chain-per-buffer sweep where a split chain fits the LDS (round 6); 0: the tiled series_phase (MDT_SQ_FAST=0: tests, A/B timing)
     int onechunk;               // 1: short slices take the one-chunk path (oc_rank_phase / oc_series_phase, mdt_short.inc) where it applies; 0: never (MDT_ONECHUNK=0: tests, A/B timing)
     long long maxlag;           // already min(maxlag, niter - 4)
