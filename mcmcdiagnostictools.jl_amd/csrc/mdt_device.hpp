@@ -100,12 +100,14 @@ constexpr int OFF_SER = OFF_PART + NWAVE * 8 * 8;         // double ser[TL+HALO]
 constexpr int LDS_SER_END = OFF_SER + (TL + HALO) * 8;
 // indicator phase view of the big region
 constexpr int BITW = TINY ? 1024 : SMALL ? 2048 : 4096;   // => draws / split_chains <= 65536 / 131072 / 262144
-constexpr int OFF_SBITS = OFF_BIG;                        // uint64 sbits[2][BITW] words of one split chain, aligned to its first draw
-constexpr int OFF_ICNT = OFF_SBITS + 2 * BITW * 8;        // double icov[2][NLAGTAB] sum over chains
+constexpr int OFF_SBITS = OFF_BIG;                        // uint64 sbits[2][BITW + IND_PAD] words of the split chains of a batch, each aligned to its first draw
+constexpr int IND_PAD = 24;                               // zero words behind a chain's bits: a read shifted by a lag <= 1000 needs no bound
+constexpr int OFF_ICNT = OFF_SBITS + 2 * (BITW + IND_PAD) * 8; // double icov[2][NLAGTAB] sum over chains
 constexpr int OFF_IDIF = OFF_ICNT + 2 * NLAGTAB * 8;      // double idif[2][NLAGTAB] sum over chains of #(I_t != I_{t+k})
 constexpr int OFF_IVAR = OFF_IDIF + 2 * NLAGTAB * 8;      // double imean[2][MAXM]
-constexpr int OFF_IPART = OFF_IVAR + 2 * MAXM * 8;         // int ipart[2][NWAVE/2][64][2]: (S, A_k) of a word segment
-constexpr int LDS_IND_END = OFF_IPART + 2 * (NWAVE / 2) * 64 * 2 * 4;
+constexpr int OFF_IPART = OFF_IVAR + 2 * MAXM * 8;         // int ipart[IND_CBX][2][NWAVE/2][64][2]: (S, A_k) of a word segment, per chain of the batch
+constexpr int IND_CBX = TINY ? 1 : SMALL ? 4 : 5;         // split chains per batch of indicator_phase (round 6): as many as fit the bit buffer, at most these
+constexpr int LDS_IND_END = OFF_IPART + IND_CBX * 2 * (NWAVE / 2) * 64 * 2 * 4;
 constexpr int LDS_BYTES = MDT_LDS_LIMIT; // 160 KiB per CU on gfx950: one big or two small workgroups
 static_assert(LDS_RANK_END <= LDS_BYTES && LDS_SER_END <= LDS_BYTES && LDS_IND_END <= LDS_BYTES, "LDS budget");
 

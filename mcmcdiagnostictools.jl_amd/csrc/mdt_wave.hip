@@ -1406,15 +1406,39 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indic
             const WV_LA unsigned long long* sbu = sb2 + u * nwU;
             int sxp = 0, akp = 0;
             if (k < kend) {
-                const int q = (int)(k >> 6), r = (int)(k & 63);
-                unsigned long long lo = sbu[i0 + q];
-                for (int i = i0; i < i1; ++i) {
+                // (round 6: the window of a lag from two 32-bit funnel shifts over the words read as halves -- v_alignbit_b32 at full rate
+                // instead of a 64-bit shift pair at a quarter of it --, four words per step with their LDS reads in flight together:
+                // lag_popcounts of mdt_indicator.inc; a unit's words are followed by zero words, so no read needs a bound)
+                typedef unsigned __attribute__((may_alias)) u32a;
+                const WV_LA u32a* W = (const WV_LA u32a*)sbu;
+                const unsigned r5 = (unsigned)k & 31u;
+                int d = 2 * i0 + (int)(k >> 5);
+                unsigned w0 = W[d], w1 = W[d + 1];
+                int i = i0;
+                for (; i + 4 <= i1; i += 4) {
+                    unsigned long long v[4];
+                    unsigned x2[4], x3[4];
+#pragma unroll
+                    for (int u2 = 0; u2 < 4; ++u2) { v[u2] = sbu[i + u2]; x2[u2] = W[d + 2 + 2 * u2]; x3[u2] = W[d + 3 + 2 * u2]; }
+#pragma unroll
+                    for (int u2 = 0; u2 < 4; ++u2) {
+                        const unsigned lo = __builtin_amdgcn_alignbit(w1, w0, r5), hi = __builtin_amdgcn_alignbit(x2[u2], w1, r5);
+                        const unsigned vl = (unsigned)v[u2], vh = (unsigned)(v[u2] >> 32);
+                        sxp += __popc(vl) + __popc(vh);
+                        akp += __popc(vl & lo) + __popc(vh & hi);
+                        w0 = x2[u2]; w1 = x3[u2];
+                    }
+                    d += 8;
+                }
+                for (; i < i1; ++i) {
                     const unsigned long long v = sbu[i];
-                    const unsigned long long hi = sbu[i + q + 1];
-                    const unsigned long long vs = r ? ((lo >> r) | (hi << (64 - r))) : lo;
-                    sxp += __popcll(v);
-                    akp += __popcll(v & vs);
-                    lo = hi;
+                    const unsigned x2 = W[d + 2], x3 = W[d + 3];
+                    const unsigned lo = __builtin_amdgcn_alignbit(w1, w0, r5), hi = __builtin_amdgcn_alignbit(x2, w1, r5);
+                    const unsigned vl = (unsigned)v, vh = (unsigned)(v >> 32);
+                    sxp += __popc(vl) + __popc(vh);
+                    akp += __popc(vl & lo) + __popc(vh & hi);
+                    w0 = x2; w1 = x3;
+                    d += 2;
                 }
             }
             __builtin_amdgcn_wave_barrier();
