@@ -759,6 +759,43 @@ def test_fewer_draws_than_splits(pkg):
     assert np.isnan(host(r)).all() and np.isnan(host(e.ess)).all() and np.isnan(host(e.rhat)).all()
 
 
+@pytest.mark.parametrize("cfg", ["", "tiny", "small", "big"])
+def test_one_draw_per_split_chain(pkg, monkeypatch, cfg):
+    """draws / split_chains == 1: the corrected variance of ONE value is 0/0 = NaN in the reference (Statistics.var,
+    src/ess_rhat.jl:529-534, src/rhat_nested.jl:168-172), so every R-hat is NaN -- until round 6 the fold merge and the moments-only
+    ranking returned variance 0 for such a chain ("all its scores are the same bits") and R-hat came out +Inf; found by the soak when
+    tail-only requests began to take the fold merge (5 draws split in three, point masses).  Every kind, the fused request and nested
+    R-hat, continuous data and ties, Float64 and Float32, every geometry, against the oracle."""
+    import warnings
+    from oracle import c_oracle as co
+    if cfg:
+        monkeypatch.setenv("MDT_CONFIG", cfg)
+    rng = np.random.default_rng(539)
+    for D, C, s in ((5, 5, 3), (1, 6, 1), (3, 4, 2)):
+        for ties in (False, True):
+            for dt in (np.float64, np.float32):
+                x = rng.standard_normal((D, C, 4))
+                if ties:
+                    x[rng.random(x.shape) < 0.5] = 0.25
+                x = x.astype(dt)
+                xd = dev(x)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    for kind in ("rank", "bulk", "tail", "basic"):
+                        got = host(pkg.rhat(xd, kind=kind, split_chains=s))
+                        want = co.ess_rhat(np.asarray(x, dtype=np.float64), kind=kind, split_chains=s)[1]
+                        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(got).all(), (D, C, s, ties, dt, kind, got, want)
+                    fused = [host(o) for o in pkg.bulk_tail(xd, split_chains=s)]
+                    assert all(np.isnan(o).all() for o in fused), (D, C, s, ties, dt, fused)
+                    if C % 2 == 0 and C >= 4:
+                        ids = np.repeat(np.arange(C // 2), 2)
+                        inds = np.arange(C, dtype=np.int32).reshape(C // 2, 2).T.copy()
+                        for kind in ("rank", "tail", "bulk"):
+                            got = host(pkg.rhat_nested(xd, ids, kind=kind, split_chains=s))
+                            want = co.rhat_nested(np.asarray(x, dtype=np.float64), inds, kind=kind, split_chains=s)
+                            assert np.array_equal(np.isnan(got), np.isnan(want)), (D, C, s, ties, dt, "nested " + kind, got, want)
+
+
 def test_fuzz_shapes_and_kinds(pkg, methods):
     """seeded random shapes / splits / data flavours through every kind, against the oracle"""
     import warnings
