@@ -300,11 +300,6 @@ struct SerZ {          // series = normal scores, already in time order in the p
 // (ranking / z-series / fold merge + indicators alone): the register allocation of one large function loses more than the
 // frames cost.
 #define MDT_PHASE_HOT MDT_PHASE
-#if defined(MDT_EXP_INLINE_SERZ) // (round-6 experiment: the z-series phase built into its callers)
-#define MDT_PHASE_SERZ __device__ __forceinline__
-#else
-#define MDT_PHASE_SERZ MDT_PHASE
-#endif
 // The dynamic LDS block reaches the phase functions as a plain pointer, but the compiler knows which symbol it is and
 // re-derives its address wherever it is used -- in a function that is not a kernel that is a LOAD from a table in
 // global memory (llvm.amdgcn.dynlds.offset.table), rematerialised inside hot loops (17 exposed L2 round trips in
@@ -514,11 +509,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(MDT_WAVES_PE
     const ZTab<T> ztab = ztab_of<T>(kp);
     const double nan = __builtin_nan("");
     if (kp.prof && tid == 0) *(long long*)(smem + OFF_PROFT) = clock64();
-#if defined(MDT_EXP_PRIO) // (round-6 experiment: static priority for a part of the waves; see DESIGN "measured and rejected")
-    if (MDT_EXP_PRIO == 1 && tid >= NT / 2) __builtin_amdgcn_s_setprio(1);       // the younger half of every workgroup
-    if (MDT_EXP_PRIO == 2 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);    // every other workgroup
-    if (MDT_EXP_PRIO == 3 && ((tid >> 6) & 1)) __builtin_amdgcn_s_setprio(1);    // the odd waves
-#endif
 
     // parameters are handed out dynamically (one atomic ticket per parameter): slowly mixing
     // parameters need more lag blocks than well-mixed ones, and a static stride leaves CUs idle
