@@ -336,7 +336,8 @@ __global__ __launch_bounds__(64) void gelman_finish_kernel(const double* __restr
 }
 
 // mcse(kind = median | quantile(p)), src/mcse.jl:93-108: S -> 0-based positions of the order statistics at the two
-// quadrature points of Beta(S p + 1, S (1 - p) + 1); one thread per parameter.  NaN ESS -> sentinel positions.
+// quadrature points of Beta(S p + 1, S (1 - p) + 1); one thread per parameter (a thread per parameter AND point measured 2.2 ms against
+// 1.6 per 100 000 parameters: the inversions are bound by Float64 issue, not by their latency; round 6).  NaN ESS -> sentinel positions.
 template <typename T>
 __global__ __launch_bounds__(64) void mcse_quantile_pos_kernel(const T* __restrict__ ess, long long P, double p, long long n,
                                                                unsigned int* __restrict__ tp) {
@@ -686,9 +687,11 @@ int run(mdt_ctx* ctx, const mdt_args* a, const void* x, Req rq) {
     const bool wave_pays = wave_raw ? wave_raw_pays(n, P, (rq.need_eb || wave_std) && ess_ok) : wave_shape_pays(n, niter, P);
     // ... and the indicator estimators whose threshold is an order statistic of x itself: ess(kind = median | quantile(p))
     // (src/ess_rhat.jl:630-633, 647-659) -- the order-statistics-only ranking and the indicator phase of ess(kind = tail)
-    const bool wave_est = (rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_QUANTILE) && rq.mode == 0 && !rq.basic && ess_ok;
-    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && ((rq.mode == 0 && !rq.basic) || wave_raw) && (rq.est == 0 || wave_est || wave_std) &&
-                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt || wave_est || wave_std) && wave_shape_fits(n, niter, m) &&
+    const bool wave_est = (rq.est == MDT_KIND_MEDIAN || rq.est == MDT_KIND_MAD || rq.est == MDT_KIND_QUANTILE) && rq.mode == 0 && !rq.basic && ess_ok;
+    // ... and the second pass of mcse(kind = median | quantile(p)) (mode 5: two order statistics at the parameter's own places)
+    const bool wave_os2 = rq.mode == 5 && !rq.basic && rq.est == 0;
+    const bool wave = wave_env != 0 && (wave_pays || wave_env == 2) && force_cfg == 0 && ((rq.mode == 0 && !rq.basic) || wave_raw || wave_os2) && (rq.est == 0 || wave_est || wave_std) &&
+                      (rq.need_eb || rq.need_rb || rq.need_et || rq.need_rt || wave_est || wave_std || wave_os2) && wave_shape_fits(n, niter, m) &&
                       maxlag <= mdtw::WV_MAXLAG && !(a->autocov == MDT_AUTOCOV_BDA && rq.want_ess) && !fft_lds &&
                       !(hook("MDT_RANK_VARIANT") && atoi(hook("MDT_RANK_VARIANT")) != 2) && P < 0x7FFFFFFFLL;
 

@@ -153,6 +153,7 @@ struct WS {
     long long p;                      // the parameter
     double xmin, xmax;
     double med, qlo, qhi;             // median and the two tail quantiles (values of T)
+    double fmed;                      // ess(kind = mad): the median of x while the second ranking runs on |x - fmed| (foldon)
     double out[4];                    // ESS bulk, R-hat bulk, ESS tail, R-hat tail
     unsigned nrounds, anyodd;         // rounds of the ranking; some rank is a half-integer
     unsigned r2q[2];                  // x <= q  <=>  doubled rank <= r2q (when zq_ok)
@@ -162,6 +163,7 @@ struct WS {
     unsigned view_bytes;              // bytes of the wave's block behind OFF_VIEW
     unsigned osonly;                  // ess(kind = tail) alone: nothing but the two quantile pairs is wanted of the ranking (round 6) -- pass B stores
                                       // only the classes of the rounds that hold them, only those rounds are ranked, the indicators come from x
+    unsigned foldon;                  // the passes over x (classify, partition, indicators) read |T(x - fmed)| instead of x
 };
 static_assert(sizeof(WS) <= WS_BYTES, "wave state block");
 #define WV_LA __attribute__((address_space(3)))
@@ -334,13 +336,24 @@ __device__ __forceinline__ RowAt row_at(unsigned r, unsigned rpc, unsigned D, lo
 }
 constexpr int UB = 8; // rows per batch of the streaming passes
 
+// StatsBase.mad's proxy (src/ess_rhat.jl:643-646): |x - median(x)| in T, the expression of SerInd in mdt_device.hpp
+template <typename T> __device__ __forceinline__ T fold_T(T v, T med, bool on) {
+    if (on) { const T d = (T)(v - med); v = d < (T)0 ? -d : d; }
+    return v;
+}
+
 // 0-based sorted places of the order statistics a request wants captured: the median pair first (rhat(kind = tail)'s fold;
 // ess(kind = median), round 6), then the quantile pairs (ess(kind = tail): both; ess(kind = quantile(p)): the same pair twice)
-__device__ __forceinline__ int wv_targets(const WV_CA KP& kp, unsigned n, unsigned (&tp)[6], bool& need_med, bool& need_q) {
-    need_med = kp.need_rt != 0 || kp.est == 4;
+__device__ __forceinline__ int wv_targets(const WV_CA KP& kp, unsigned n, long long p, unsigned (&tp)[6], bool& need_med, bool& need_q) {
+    need_med = kp.need_rt != 0 || kp.est == 4 || kp.est == 6;
     need_q = (kp.need_et || kp.est == 7) && kp.ess_ok;
 #pragma unroll
     for (int t = 0; t < 6; ++t) tp[t] = 0u;
+    if (kp.mode == 5) { // second pass of mcse(kind = median | quantile(p)), src/mcse.jl:109-117: the parameter's own two places
+        need_med = false; need_q = false;
+        tp[0] = kp.tpos_arr[2 * p]; tp[1] = kp.tpos_arr[2 * p + 1];
+        return 2;
+    }
     const unsigned ql0 = (unsigned)(kp.q_j[0] - 1), ql1 = (unsigned)kp.q_j[0], qh0 = (unsigned)(kp.q_j[1] - 1), qh1 = (unsigned)kp.q_j[1];
     if (need_med && need_q) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; tp[2] = ql0; tp[3] = ql1; tp[4] = qh0; tp[5] = qh1; return 6; }
     if (need_med) { tp[0] = (n - 1u) / 2u; tp[1] = n / 2u; return 2; }
@@ -360,6 +373,8 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
     const unsigned n = (unsigned)kp.n, D = (unsigned)kp.D, C = (unsigned)kp.C;
     const long long cs = kp.cstride;
     const double inf = __builtin_inf();
+    const bool fo = rflu(ws->foldon) != 0u;
+    const T fm = (T)rfld(ws->fmed);
     // ---- 128 values spread over the slice, sorted by the wave
     {
         double a, b;
@@ -367,8 +382,8 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
             const unsigned i0 = (unsigned)lane, i1 = 64u + (unsigned)lane;
             const unsigned q0 = ((2u * i0 + 1u) * n) >> 8, q1 = ((2u * i1 + 1u) * n) >> 8;
             const unsigned c0 = q0 / D, c1 = q1 / D;
-            a = (double)xp[(long long)c0 * cs + (q0 - c0 * D)];
-            b = (double)xp[(long long)c1 * cs + (q1 - c1 * D)];
+            a = (double)fold_T<T>(xp[(long long)c0 * cs + (q0 - c0 * D)], fm, fo);
+            b = (double)fold_T<T>(xp[(long long)c1 * cs + (q1 - c1 * D)], fm, fo);
             a = (a - a == 0.0) ? a : inf;
             b = (b - b == 0.0) ? b : inf;
         }
@@ -412,7 +427,7 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const unsigned r = r0 + (unsigned)u;
-            vv[u] = (double)xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad];
+            vv[u] = (double)fold_T<T>(xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad], fm, fo);
         }
     };
     double xmin = inf, xmax = -inf;
@@ -502,12 +517,14 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
     const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
     const long long cs = kp.cstride;
     const unsigned rpc = (D + 63u) >> 6, NRW = C * rpc;
+    const bool fo = rflu(ws->foldon) != 0u;
+    const T fm = (T)rfld(ws->fmed);
     auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); }; // src/utils.jl:29-36
     auto load_batch = [&](unsigned r0, double (&vv)[UB]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const unsigned r = r0 + (unsigned)u;
-            vv[u] = (double)xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad];
+            vv[u] = (double)fold_T<T>(xp[row_at(r < NRW ? r : NRW - 1u, rpc, D, cs, lane).ad], fm, fo);
         }
     };
     // Order statistics only (ess(kind = tail) alone, round 6): the classes of the rounds that hold one of the four wanted places are
@@ -526,7 +543,7 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
             const unsigned g0 = cst[cA], g1 = cB < (unsigned)NCLS ? (unsigned)cst[cB] : n_;
             unsigned t6[6];
             bool nm_, nq_;
-            const int nt_ = wv_targets(kp, n_, t6, nm_, nq_);
+            const int nt_ = wv_targets(kp, n_, ws->p, t6, nm_, nq_);
             bool tin = false;
 #pragma unroll
             for (int t = 0; t < 6; ++t) tin = tin || (t < nt_ && t6[t] >= g0 && t6[t] < g1);
@@ -595,7 +612,7 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
     const unsigned nrounds = rflu(ws->nrounds);
     bool need_med, need_q;
     unsigned tp[6]; // 0-based places of the order statistics: median pair first, then the quantile pairs
-    const int ntgt = wv_targets(kp, n, tp, need_med, need_q);
+    const int ntgt = wv_targets(kp, n, ws->p, tp, need_med, need_q);
     const bool osonly = rflu(ws->osonly) != 0u; // (only the rounds that hold a wanted place are ranked; no rank list, no sorted copy)
     const bool need_ra = (kp.need_eb || kp.need_rb || need_q) && !osonly; // ranks in time order: the z-series, and the tail indicators
     if (lane < WV_MAXM) { // per split chain: fill of its rank list; pooled index of its first draw (src/utils.jl:29-36)
@@ -795,7 +812,9 @@ WV_PHASE void ph_rounds(unsigned wbase_arg) {
             if (osonly) zq_ok = 0; // (no rank was listed: the indicator phase compares x with the quantiles themselves)
         }
     }
-    if (kp.est == 4) { qq[0] = medT; qq[1] = medT; zq_ok = 0; } // ess(kind = median): the indicator of x <= median (src/ess_rhat.jl:630-633), both thresholds the same
+    if (kp.est == 4 || kp.est == 6) { qq[0] = medT; qq[1] = medT; zq_ok = 0; } // ess(kind = median): the indicator of x <= median (src/ess_rhat.jl:630-633), both thresholds the same;
+                                                                             // kind = mad: the same of |x - median(x)| once the second ranking has run
+    if (kp.mode == 5 && lane == 0) ws->out[2] = (double)(T)(((T)ostat[1] - (T)ostat[0]) / (T)2); // _mcse_quantile: (xu - xl) / 2 in T
     if (lane == 0) {
         ws->anyodd = anyodd; ws->med = (double)medT; ws->qlo = (double)qq[0]; ws->qhi = (double)qq[1];
         ws->zq_ok = zq_ok; ws->r2q[0] = r2q[0]; ws->r2q[1] = r2q[1];
@@ -1347,6 +1366,8 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indic
         const bool byrank = rfl(ws->zq_ok) != 0;
         const unsigned r2q0 = rflu(ws->r2q[0]), r2q1 = rflu(ws->r2q[1]);
         const T qloT = (T)rfld(ws->qlo), qhiT = (T)rfld(ws->qhi);
+        const bool fo = rflu(ws->foldon) != 0u;
+        const T fm = (T)rfld(ws->fmed);
         for (int i = lane; i < 2 * m * nwU; i += 64) sb2[i] = 0ull;
         lds_fence();
         for (int j = 0; j < m; ++j) {
@@ -1374,7 +1395,7 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indic
                 const WV_GA T* xr = xp + (long long)c * cs + row0(k);
                 T xv[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; xv[b] = xr[t < niter ? t : niter - 1u]; }
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; xv[b] = fold_T<T>(xr[t < niter ? t : niter - 1u], fm, fo); }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
@@ -1577,14 +1598,19 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         if (lane == 0) {
             ws->p = p;
             ws->xp = (unsigned long long)((const T*)kp.x + p * kp.pstride);
-            ws->fallback = 0; ws->zq_ok = 0; ws->bits_done = 0; ws->anyodd = 0u; ws->nrounds = 0u;
-            ws->osonly = ((kp.need_et || kp.est) && kp.ess_ok && !kp.need_eb && !kp.need_rb && !kp.need_rt && wa.osonly) ? 1u : 0u;
+            ws->fallback = 0; ws->zq_ok = 0; ws->bits_done = 0; ws->anyodd = 0u; ws->nrounds = 0u; ws->foldon = 0u; ws->fmed = 0.0;
+            ws->osonly = ((((kp.need_et || kp.est) && kp.ess_ok) || kp.mode == 5) && !kp.need_eb && !kp.need_rb && !kp.need_rt && wa.osonly) ? 1u : 0u;
             ws->out[0] = nan; ws->out[1] = nan; ws->out[2] = nan; ws->out[3] = nan;
         }
         lds_fence();
         WPROF(0);
         const int stop = wa.stop; // diagnostics: the parameter ends after phase `stop`, its outputs stay NaN
         WDBG(10);
+        if (kp.mode == 5 && kp.tpos_arr[2 * p] == 0xFFFFFFFFu) { // mcse quantile of a NaN ESS (src/mcse.jl:95-97)
+            if (lane == 0) store_out<T>(kp.out_eb, p, nan);
+            lds_fence();
+            continue;
+        }
         if (kp.basic) {
             // raw draws (round 6): ess / rhat / ess_rhat(kind = basic) and mcse(kind = mean) -- no ranking, the series phase alone
             const unsigned nblk = ((unsigned)kp.niter + 63u) >> 6;
@@ -1631,7 +1657,16 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
             if (stop != 2) {
                 ph_rounds<T>(wbase);
                 WDBG(40);
-                if (stop != 3) {
+                if (kp.est == 6) {
+                    // ess(kind = mad): the median of |x - median(x)| by a second ranking of the same kind -- the three passes read the
+                    // folded value where they read x (order statistics only: two or three rounds of the scratch are written)
+                    if (lane == 0) { ws->fmed = ws->med; ws->foldon = 1u; }
+                    lds_fence();
+                    ph_classify<T>(wbase);
+                    fb = rfl(ws->fallback) != 0;
+                    if (!fb) { ph_partition<T>(wbase); ph_rounds<T>(wbase); }
+                }
+                if (!fb && stop != 3) {
                     if (kp.need_rt) { ph_fold<T>(wbase); fb = rfl(ws->fallback) != 0; }
                     WDBG(50);
                     if (!fb && stop != 4) {
@@ -1656,7 +1691,8 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
         WDBG(70);
         if (fb) { // the general kernel, queued behind this launch, serves the parameter
             if (lane == 0) { const int i = atomicAdd(wa.fb_count, 1); wa.fb_list[i] = (unsigned)p; }
-        } else if (kp.est) { // ess(kind = median | quantile(p)): the ESS of the one indicator (the two "tails" are the same series)
+        } else if (kp.est || kp.mode == 5) { // ess(kind = median | mad | quantile(p)): the ESS of the one indicator (the two "tails" are the same series);
+                                             // mode 5: half the distance of the two order statistics
             if (lane == 0) store_out<T>(kp.out_eb, p, ws->out[2]);
         } else if (lane == 0) {
             const double eb_ = ws->out[0], rb_ = ws->out[1], et_ = ws->out[2], rt_ = ws->out[3];

@@ -1698,7 +1698,8 @@ def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, me
     """Round 6: ess(kind = tail) alone (src/ess_rhat.jl:301-311) needs nothing of the ranking but two pairs of order statistics: the
     wave-per-parameter kernel then stores and ranks only the rounds that hold them and takes the indicators from x.  MDT_WAVE_OSONLY=0
     ranks everything and takes the indicators from the ranks: the same bits (the indicator sums are exact integers), on continuous
-    data, heavy ties, Float32, every split; the general kernels (MDT_WAVE=0) and the oracle agree."""
+    data, heavy ties, Float32, every split; the general kernels (MDT_WAVE=0) and the oracle agree.  ess(kind = median | quantile(p)) take the
+    same route with their one pair, ess(kind = mad) takes it twice: the second time the passes read |x - median(x)| where they read x."""
     import warnings
     from oracle import c_oracle as co
     rng = np.random.default_rng(707)
@@ -1721,7 +1722,8 @@ def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, me
                     warnings.simplefilter("ignore")
                     outs[tag] = [host(pkg.ess(xd, kind="tail", split_chains=s)), host(pkg.ess(xd, kind="tail", split_chains=s, tail_prob=0.3, maxlag=20, relative=True)),
                                  host(pkg.ess(xd, kind="tail", split_chains=s, autocov_method=methods["fft"])),
-                                 host(pkg.ess(xd, kind=np.median, split_chains=s)), host(pkg.ess(xd, kind=pkg.Quantile(0.37), split_chains=s, maxlag=60))]
+                                 host(pkg.ess(xd, kind=np.median, split_chains=s)), host(pkg.ess(xd, kind=pkg.Quantile(0.37), split_chains=s, maxlag=60)),
+                                 host(pkg.ess(xd, kind="mad", split_chains=s))]
             for k in ("MDT_WAVE", "MDT_WAVE_OSONLY"):
                 monkeypatch.delenv(k, raising=False)
             for a, b, c in zip(outs["only"], outs["full"], outs["wg"]):
@@ -1731,6 +1733,7 @@ def test_wave_path_tail_ess_alone_ranks_only_the_rounds_of_its_quantiles(pkg, me
                 e, _ = co.ess_rhat(xs, kind="tail", split_chains=s)
                 assert_close(outs["only"][0], e, RTOL64, f"{what} s={s} oracle")
                 assert_close(outs["only"][3], co.ess_estimator(xs, "median", split_chains=s), RTOL64, f"{what} s={s} oracle median")
+                assert_close(outs["only"][5], co.ess_estimator(xs, "mad", split_chains=s), RTOL64, f"{what} s={s} oracle mad")
 
 
 def test_wave_path_raw_draws_match_the_general_path(pkg, methods, monkeypatch):

@@ -140,6 +140,10 @@ while time.time() - t0 < budget:
         for est, kind in (("median", np.median), ("mad", "mad")):
             got = pkg.ess(xd, kind=kind, autocov_method=methods[m], split_chains=s, maxlag=ml)
             check(host(got), co.ess_estimator(x, est, autocov=m, split_chains=s, maxlag=ml), tol, what + " " + est, True, short)  # (an indicator series is discrete whatever x is)
+        if D // s > 4:  # mcse(kind = median | quantile(p)), src/mcse.jl:66-118: two passes (round 6: both on the wave kernel for short slices)
+            pq = float(rng.choice([0.5, 0.1, 0.83]))
+            check(host(pkg.mcse(xd, kind=np.median, autocov_method=methods[m], split_chains=s, maxlag=ml)), co.mcse_quantile(x, "median", 0.5, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse median", True, short)
+            check(host(pkg.mcse(xd, kind=pkg.Quantile(pq), autocov_method=methods[m], split_chains=s, maxlag=ml)), co.mcse_quantile(x, "quantile", pq, autocov=m, split_chains=s, maxlag=ml), tol, what + f" mcse quantile {pq}", True, short)
         if D // s > 4 and not f32 and fl != "offset":  # the std proxy (x - mean)^2: ess(kind = std), mcse(kind = std) (round 6: on the wave kernel too)
             check(host(pkg.ess(xd, kind=np.std, autocov_method=methods[m], split_chains=s, maxlag=ml)), co.ess_estimator(x, "std", autocov=m, split_chains=s, maxlag=ml), tol, what + " ess std", disc, short)
             check(host(pkg.mcse(xd, kind=np.std, autocov_method=methods[m], split_chains=s, maxlag=ml)), co.mcse_std(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " mcse std", disc, short)
@@ -156,4 +160,4 @@ while time.time() - t0 < budget:
                 mm, rr = pkg.mcse_rhat_nested(xd, ids, kind="rank", split_chains=s, maxlag=ml, autocov_method=methods[m])
                 assert_close(host(rr), want_n, tol, what + " fused nested")
                 check(host(mm), co.mcse_mean(x, autocov=m, split_chains=s, maxlag=ml), tol, what + " fused mcse", disc)
-print(f"fuzz soak: {it} random requests x 8-9 calls each agreed with the oracle in {time.time() - t0:.0f} s ({ties_seen} exact Geyer ties on discrete data tolerated)")
+print(f"fuzz soak: {it} random requests x 10-11 calls each agreed with the oracle in {time.time() - t0:.0f} s ({ties_seen} exact Geyer ties on discrete data tolerated)")
