@@ -354,7 +354,7 @@ def other_configs(pkg, device, steps, warmup):
 
 def request_kinds(pkg, device, steps=3):
     """Partial requests -- what the reference's API hands out one call at a time (`ess(kind = :tail)`, `rhat(kind = :tail)`,
-    `mcse(kind = mean)`, `kind = :basic`, `ess(kind = median)`) -- on config 1's slice shape at scale and on config 2's: time per
+    `mcse(kind = mean)`, `kind = :basic`, `ess(kind = median | mad)`, `mcse(kind = median)`) -- on config 1's slice shape at scale and on config 2's: time per
     call on the default path and, beside it, on the path that served the request until round 5 (the library's own switch, behind
     the test-hooks gate the bench sets): round 6 stopped such requests from paying for pipeline stages they do not need."""
     import warnings
@@ -389,6 +389,8 @@ def request_kinds(pkg, device, steps=3):
     rows["mcse_mean"] = both(lambda: pkg.mcse(x), {"MDT_WAVE": "0"})
     rows["ess_tail"] = both(lambda: pkg.ess(x, kind="tail"), {"MDT_WAVE_OSONLY": "0"})
     rows["ess_median"] = both(lambda: pkg.ess(x, kind=np.median), {"MDT_WAVE": "0"})
+    rows["ess_mad"] = both(lambda: pkg.ess(x, kind="mad"), {"MDT_WAVE": "0"})
+    rows["mcse_median"] = both(lambda: pkg.mcse(x, kind=np.median), {"MDT_WAVE": "0"})
     pick = np.array([0, 5, P // 2 + 6, P - 1])
     xs = x_pcd[torch.as_tensor(pick, device=device)].permute(2, 1, 0).cpu().numpy()
     with warnings.catch_warnings():
