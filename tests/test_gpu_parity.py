@@ -431,7 +431,7 @@ def test_host_buffers_in_blocks(pkg, monkeypatch):
         assert np.array_equal(host(pkg.rhat(x[:, :, :4])), host(pkg.rhat(dev(x[:, :, :4]))))
 
 
-def test_mcmcchains_storage_order(pkg):
+def test_mcmcchains_storage_order(pkg, monkeypatch):
     """(iterations, parameters, chains) input -- MCMCChains storage -- read IN PLACE through chain_stride /
     param_stride (no permuted copy), and through the device-side permutation helper: bit-equal to the dense call"""
     import torch
@@ -457,6 +457,19 @@ def test_mcmcchains_storage_order(pkg):
             assert np.array_equal(host(m), host(pkg.mcse(dev(x))))
             for kind in ("basic", "tail", np.median):
                 assert np.array_equal(host(pkg.ess(view, kind=kind)), host(pkg.ess(dev(x), kind=kind)))
+            if shape[0] * shape[1] <= 8192:
+                # the same through the wave-per-parameter kernel (forced: seven parameters do not fill it), every request kind it serves
+                monkeypatch.setenv("MDT_WAVE", "2")
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    for kind in ("basic", "bulk", "tail", np.median, "mad", np.std, pkg.Quantile(0.3)):
+                        assert np.array_equal(host(pkg.ess(view, kind=kind)), host(pkg.ess(dev(x), kind=kind))), kind
+                    for kind in (np.mean, np.std, np.median, pkg.Quantile(0.7)):
+                        assert np.array_equal(host(pkg.mcse(view, kind=kind)), host(pkg.mcse(dev(x), kind=kind))), kind
+                    for u, w in zip(pkg.bulk_tail(view), pkg.bulk_tail(dev(x))):
+                        assert np.array_equal(host(u), host(w), equal_nan=True)
+                monkeypatch.delenv("MDT_WAVE")
             # nothing of the size of x was allocated on the way (outputs only)
             assert torch.cuda.memory_allocated() - before < x.nbytes // 4
             # the out-of-place helper still works
