@@ -362,7 +362,9 @@ __device__ __forceinline__ int wv_targets(const WV_CA KP& kp, unsigned n, long l
 }
 
 // ------------------------------------------------------------------ sample -> splitters; pass A: classes, histogram, range; rounds
-WV_PHASE void ph_classify(unsigned wbase_arg) {
+// (FOLD: the slice is read as |T(x - fmed)| -- the second ranking of ess(kind = mad); its own instantiation: as a run-time select in
+// the loads it cost every request of the kernel 3 - 7 %)
+template <typename T, bool FOLD = false> __device__ __attribute__((noinline)) void ph_classify(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA double* sp = (WV_LA double*)(wb + OFF_SP);
     WV_LA float* iw = (WV_LA float*)(wb + OFF_IW);
@@ -373,8 +375,8 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
     const unsigned n = (unsigned)kp.n, D = (unsigned)kp.D, C = (unsigned)kp.C;
     const long long cs = kp.cstride;
     const double inf = __builtin_inf();
-    const bool fo = rflu(ws->foldon) != 0u;
-    const T fm = (T)rfld(ws->fmed);
+    constexpr bool fo = FOLD;
+    const T fm = FOLD ? (T)rfld(ws->fmed) : (T)0;
     // ---- 128 values spread over the slice, sorted by the wave
     {
         double a, b;
@@ -507,7 +509,7 @@ WV_PHASE void ph_classify(unsigned wbase_arg) {
 }
 
 // ------------------------------------------------------------------ pass B: the slice, class-sorted, into the scratch
-WV_PHASE void ph_partition(unsigned wbase_arg) {
+template <typename T, bool FOLD = false> __device__ __attribute__((noinline)) void ph_partition(unsigned wbase_arg) {
     WV_ENTER(wbase_arg);
     WV_LA unsigned* ccur = (WV_LA unsigned*)(wb + OFF_CCUR);
     WV_LA unsigned char* clsb = (WV_LA unsigned char*)(wb + OFF_VAL);
@@ -517,8 +519,8 @@ WV_PHASE void ph_partition(unsigned wbase_arg) {
     const unsigned niter = (unsigned)kp.niter, s = (unsigned)kp.s, rem = (unsigned)kp.rem;
     const long long cs = kp.cstride;
     const unsigned rpc = (D + 63u) >> 6, NRW = C * rpc;
-    const bool fo = rflu(ws->foldon) != 0u;
-    const T fm = (T)rfld(ws->fmed);
+    constexpr bool fo = FOLD;
+    const T fm = FOLD ? (T)rfld(ws->fmed) : (T)0;
     auto row0 = [&](unsigned k) -> unsigned { return k * niter + (k < rem ? k : rem); }; // src/utils.jl:29-36
     auto load_batch = [&](unsigned r0, double (&vv)[UB]) {
 #pragma unroll
@@ -1395,7 +1397,11 @@ template <typename T, int NB> __device__ __attribute__((noinline)) void ph_indic
                 const WV_GA T* xr = xp + (long long)c * cs + row0(k);
                 T xv[NB];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; xv[b] = fold_T<T>(xr[t < niter ? t : niter - 1u], fm, fo); }
+                for (int b = 0; b < NB; ++b) { const unsigned t = 64u * (unsigned)b + (unsigned)lane; xv[b] = xr[t < niter ? t : niter - 1u]; }
+                if (fo) { // (wave-uniform: ess(kind = mad))
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) xv[b] = fold_T<T>(xv[b], fm, true);
+                }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     const bool okt = 64u * (unsigned)b + (unsigned)lane < niter;
@@ -1662,9 +1668,9 @@ __global__ __launch_bounds__(NTHREADS) void wave_kernel(const KP* __restrict__ k
                     // folded value where they read x (order statistics only: two or three rounds of the scratch are written)
                     if (lane == 0) { ws->fmed = ws->med; ws->foldon = 1u; }
                     lds_fence();
-                    ph_classify<T>(wbase);
+                    ph_classify<T, true>(wbase);
                     fb = rfl(ws->fallback) != 0;
-                    if (!fb) { ph_partition<T>(wbase); ph_rounds<T>(wbase); }
+                    if (!fb) { ph_partition<T, true>(wbase); ph_rounds<T>(wbase); }
                 }
                 if (!fb && stop != 3) {
                     if (kp.need_rt) { ph_fold<T>(wbase); fb = rfl(ws->fallback) != 0; }
