@@ -23,7 +23,7 @@ module MCMCDiagnosticToolsROC
 
 using Statistics: Statistics
 
-export ess, rhat, ess_rhat, rhat_nested, mcse, mcse_rhat_nested, bfmi, gelmandiag, status, shard_bounds, samples_from_chains, UnsupportedOnDevice
+export ess, rhat, ess_rhat, bulk_tail, rhat_nested, mcse, mcse_rhat_nested, bfmi, gelmandiag, status, shard_bounds, samples_from_chains, UnsupportedOnDevice
 export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
 
 const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")
@@ -315,6 +315,42 @@ function ess_rhat(x::Samples; kind::Symbol=:rank, kwargs...)
     haskey(_KIND, kind) || throw(ArgumentError("the `kind` `$kind` is not supported by `ess_rhat`"))
     S, R = _ess_rhat(x, kind, 3; kwargs...)
     return (; ess=S, rhat=R)
+end
+
+"""
+    bulk_tail(samples; relative=false, autocov_method=AutocovMethod(), split_chains=2, maxlag=250, tail_prob=1//10, devices=nothing)
+
+`ess_rhat(samples; kind=:bulk)` and `ess_rhat(samples; kind=:tail)` from ONE pass over `samples` (`mdt_bulk_tail`: the pooled
+ranking of `x` is shared; `src/ess_rhat.jl:604-616`) -- what a summary table asks for, and the BASELINE metric.  Returns
+`(; ess_bulk, ess_tail, rhat_bulk, rhat_tail)`; `rhat(samples)` (`kind = :rank`) is `max.(rhat_tail, rhat_bulk)` (`:416-420`).
+The reference has no fused counterpart: it runs the two kinds one after the other.
+"""
+function bulk_tail(x::Samples; relative::Bool=false, autocov_method::AbstractAutocovMethod=AutocovMethod(), split_chains::Int=2,
+                   maxlag::Int=250, tail_prob::Real=1//10, devices=nothing)
+    if _all_missing(x)
+        m = _missing_out(x)
+        return (; ess_bulk=m, ess_tail=m, rhat_bulk=m, rhat_tail=m)
+    end
+    pr = _prepare(x)
+    T = _valtype(x isa AbstractVector{<:AbstractArray} ? first(x) : x)
+    D, C, P = size(pr)
+    niter = D ÷ split_chains
+    !(niter > 4) && @warn "number of draws after splitting must be >4 but is $niter. ESS cannot be computed."
+    Sb, St, Rb, Rt = _newout(pr, P), _newout(pr, P), _newout(pr, P), _newout(pr, P)
+    TP = float(promote_type(T, typeof(tail_prob)))          # src/ess_rhat.jl:305-307, in the caller's arithmetic (see _ess_rhat)
+    pl, pu = Float64(convert(TP, tail_prob / 2)), Float64(convert(TP, 1 - tail_prob / 2))
+    a0 = _args_for(pr, MdtArgs(D, C, P, T === Float32 ? 1 : 0, pr.location, 0, 3, _code(autocov_method),
+                               split_chains, relative, 1, maxlag, Float64(tail_prob), C_NULL), pr.shards)
+    a = _with_layout(a0, a0.chain_stride, a0.param_stride, a0.x_shards, pl, pu)
+    x3, sh, h = pr.x3, pr.shards, _ctx_for(devices, pr)
+    GC.@preserve x3 sh Sb St Rb Rt begin
+        _locked() do
+            _check(h, ccall((:mdt_bulk_tail, libmdt), Cint,
+                            (Ptr{Cvoid}, Ref{MdtArgs}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                            h, a, _xptr(pr), _ptr(Sb), _ptr(St), _ptr(Rb), _ptr(Rt)), maxlag)
+        end
+    end
+    return (; ess_bulk=_out(x, pr, Sb), ess_tail=_out(x, pr, St), rhat_bulk=_out(x, pr, Rb), rhat_tail=_out(x, pr, Rt))
 end
 
 # _validate_superchain_ids (src/rhat_nested.jl:68-81) -> K x S, 0-based, column-major

@@ -287,6 +287,20 @@ Random.seed!(20261004)
         @test ROC.bfmi(e2) ≈ [0.6, 0.6] && ROC.bfmi(permutedims(e2); dims=2) ≈ [0.6, 0.6]
     end
 
+    @testset "bulk_tail: the two kinds from one pass are the two kinds (src/ess_rhat.jl:604-616)" begin
+        x = randn(400, 4, 6)
+        for split_chains in (1, 2, 3), am in (ROC.AutocovMethod(), ROC.FFTAutocovMethod())
+            bt = ROC.bulk_tail(x; split_chains, autocov_method=am)
+            b = ROC.ess_rhat(x; kind=:bulk, split_chains, autocov_method=am)
+            t = ROC.ess_rhat(x; kind=:tail, split_chains, autocov_method=am)
+            @test bt.rhat_bulk == b.rhat && bt.rhat_tail == t.rhat              # R-hat: the same bits on every path
+            @test isapprox(bt.ess_bulk, b.ess; rtol=1e-9) && isapprox(bt.ess_tail, t.ess; rtol=1e-9)
+            @test ROC.rhat(x; split_chains) == max.(bt.rhat_tail, bt.rhat_bulk)  # kind = :rank (src/ess_rhat.jl:416-420)
+        end
+        @test ROC.bulk_tail(rand(Float32, 100, 2, 3)).ess_bulk isa Vector{Float32}
+        @test ROC.bulk_tail(randn(100, 4)).rhat_tail isa Float64
+        @test_throws DomainError ROC.bulk_tail(x; maxlag=0)
+    end
     @testset "requests from several tasks queue on the context" begin
         x = randn(400, 4, 8)
         want = ROC.ess_rhat(x)

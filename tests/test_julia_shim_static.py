@@ -1,0 +1,121 @@
+"""CPU: the Julia shim (julia/MCMCDiagnosticToolsROC.jl) cannot be executed in this image -- there is no Julia -- so what can be
+held to the C-ABI without running it is held here, by reading its text: every `ccall` names a symbol include/mdt_hip.h declares,
+passes as many arguments as the prototype takes (and as many values as it lists types), and `struct MdtArgs` has the fields of
+`mdt_args` in the header's order with types of the same size.  A static check, not a run: runtests.jl stays the real test."""
+import os
+import re
+
+import __graft_entry__ as g
+
+ROOT = g.ROOT
+JL = os.path.join(ROOT, "julia", "MCMCDiagnosticToolsROC.jl")
+HDR = os.path.join(ROOT, "include", "mdt_hip.h")
+
+
+def _strip_c_comments(src):
+    return re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+
+
+def _split_top_level(s):
+    """split at commas outside brackets"""
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _balanced(text, start):
+    """text[start] == '(' -> index behind its closing bracket"""
+    depth = 0
+    for i in range(start, len(text)):
+        if text[i] == "(":
+            depth += 1
+        elif text[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return i + 1
+    raise AssertionError("unbalanced brackets")
+
+
+def header_prototypes():
+    src = _strip_c_comments(open(HDR).read())
+    protos = {}
+    for m in re.finditer(r"\b(mdt_[a-z_]+)\s*\(", src):
+        end = _balanced(src, m.end() - 1)
+        params = src[m.end():end - 1].strip()
+        protos[m.group(1)] = 0 if params in ("", "void") else len(_split_top_level(params))
+    return protos
+
+
+def julia_ccalls():
+    src = re.sub(r"#.*", "", open(JL).read())  # (no '#' inside the strings of the shim's ccall sites)
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(mdt_[a-z_]+),\s*libmdt\)", src):
+        start = src.rfind("ccall(", 0, m.end())
+        end = _balanced(src, start + len("ccall"))
+        args = _split_top_level(src[start + len("ccall("):end - 1])
+        # args: (sym, lib), rettype, (argtypes...), values...
+        types = args[2].strip()
+        assert types.startswith("(") and types.endswith(")"), (m.group(1), types)
+        inner = types[1:-1].strip()
+        tl = [t for t in _split_top_level(inner) if t]
+        calls.append((m.group(1), args[1], tl, args[3:]))
+    return calls
+
+
+def test_every_ccall_names_a_declared_symbol_with_the_prototypes_arity():
+    protos = header_prototypes()
+    calls = julia_ccalls()
+    assert len(calls) >= 12
+    for name, ret, types, values in calls:
+        assert name in protos, f"{name}: not declared in include/mdt_hip.h"
+        assert len(types) == protos[name], f"{name}: {len(types)} argument types in the shim, {protos[name]} parameters in the header"
+        assert len(values) == len(types), f"{name}: {len(values)} values for {len(types)} types"
+        assert ret in ("Cint", "Cstring"), (name, ret)
+
+
+def test_the_hot_path_entry_points_are_bound():
+    bound = {c[0] for c in julia_ccalls()}
+    for name in ("mdt_ctx_create", "mdt_ctx_create_multi", "mdt_ctx_status", "mdt_ctx_reserve", "mdt_last_error", "mdt_shard_bounds",
+                 "mdt_ess_rhat", "mdt_bulk_tail", "mdt_rhat_nested", "mdt_mcse_nested", "mdt_mcse_mean", "mdt_mcse_std", "mdt_mcse_quantile",
+                 "mdt_bfmi", "mdt_gelmandiag"):
+        assert name in bound, name
+
+
+C_SIZES = {"int64_t": 8, "int32_t": 4, "double": 8, "void*": 8, "const void* const*": 8}
+JL_SIZES = {"Int64": 8, "Int32": 4, "Float64": 8}
+
+
+def test_mdtargs_mirrors_the_header_struct_field_by_field():
+    hdr = _strip_c_comments(open(HDR).read())
+    body = re.search(r"typedef struct mdt_args \{(.*?)\} mdt_args;", hdr, flags=re.S).group(1)
+    cfields = []
+    for decl in [d.strip() for d in body.split(";") if d.strip()]:
+        m = re.match(r"(.*?[\s\*])([a-z_0-9]+(?:\s*,\s*[a-z_0-9]+)*)$", decl, flags=re.S)
+        ctype = re.sub(r"\s+", " ", m.group(1)).strip().replace(" *", "*")
+        for name in [n.strip() for n in m.group(2).split(",")]:
+            cfields.append((name, C_SIZES[ctype]))
+    jl = re.sub(r"#.*", "", open(JL).read())
+    jbody = re.search(r"struct MdtArgs\n(.*?)\nend", jl, flags=re.S).group(1)
+    jfields = []
+    for line in [l.strip() for l in jbody.splitlines() if l.strip()]:
+        name, jtype = [t.strip() for t in line.split("::")]
+        jfields.append((name, 8 if jtype.startswith("Ptr") else JL_SIZES[jtype]))
+    assert [n for n, _ in jfields] == [n for n, _ in cfields]
+    assert [s for _, s in jfields] == [s for _, s in cfields]
+    # the same 120 bytes tests/test_capi_symbols.py holds the ctypes mirror to (both layouts have no padding: 8-byte fields on 8-byte offsets)
+    off = 0
+    for _, size in cfields:
+        assert off % size == 0
+        off += size
+    assert off == 120
