@@ -84,6 +84,41 @@ def test_every_ccall_names_a_declared_symbol_with_the_prototypes_arity():
         assert ret in ("Cint", "Cstring"), (name, ret)
 
 
+def header_param_types():
+    src = _strip_c_comments(open(HDR).read())
+    out = {}
+    for m in re.finditer(r"\b(mdt_[a-z_]+)\s*\(", src):
+        end = _balanced(src, m.end() - 1)
+        params = re.sub(r"\s+", " ", src[m.end():end - 1]).strip()
+        out[m.group(1)] = [] if params in ("", "void") else [re.sub(r"\s*[A-Za-z_0-9]+$", "", p_).strip() for p_ in _split_top_level(params)]
+    return out
+
+
+def _c_class(t):
+    if "*" in t:
+        return "ptr"
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64"}[t.replace("const ", "")]
+
+
+def _jl_class(t):
+    if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64"}[t]
+
+
+def test_every_ccall_passes_the_prototypes_argument_classes():
+    """pointer / 32-bit integer / 64-bit integer / double, position by position: what the x86-64 calling convention cares about"""
+    ctypes_ = header_param_types()
+    for name, _, types, _ in julia_ccalls():
+        want = [_c_class(t) for t in ctypes_[name]]
+        got = [_jl_class(t) for t in types]
+        assert got == want, (name, types, ctypes_[name])
+        # a struct goes by reference as Ref{MdtArgs}, never by value
+        for jt, ct in zip(types, ctypes_[name]):
+            if "mdt_args" in ct:
+                assert jt == "Ref{MdtArgs}", (name, jt)
+
+
 def test_the_hot_path_entry_points_are_bound():
     bound = {c[0] for c in julia_ccalls()}
     for name in ("mdt_ctx_create", "mdt_ctx_create_multi", "mdt_ctx_status", "mdt_ctx_reserve", "mdt_last_error", "mdt_shard_bounds",
@@ -119,3 +154,56 @@ def test_mdtargs_mirrors_the_header_struct_field_by_field():
         assert off % size == 0
         off += size
     assert off == 120
+
+
+def _julia_code_only(src):
+    """comments, strings and character literals blanked out"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        if src.startswith('"""', i):
+            j = src.index('"""', i + 3)
+            i = j + 3
+        elif src[i] == '"':
+            j = i + 1
+            while src[j] != '"':
+                if src[j] == "\\":
+                    j += 1
+                j += 1
+            out.append('""')
+            i = j + 1
+        elif src[i] == "#":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src[i] == "'" and i + 2 < n and (src[i + 2] == "'" or (src[i + 1] == "\\" and src[i + 3] == "'")):
+            i = src.index("'", i + 2 if src[i + 1] != "\\" else i + 3) + 1
+        else:
+            out.append(src[i])
+            i += 1
+    return "".join(out)
+
+
+def test_blocks_and_brackets_balance_in_the_julia_sources():
+    """a crude stand-in for the parser this image lacks: outside brackets (generators, comprehensions and a[end] live inside them)
+    every block opener has its `end`, and every bracket closes -- an edit that drops an `end` fails here, not on a user's machine"""
+    for rel in ("MCMCDiagnosticToolsROC.jl", os.path.join("test", "runtests.jl"), "gen_reference_golden.jl"):
+        code = _julia_code_only(open(os.path.join(ROOT, "julia", rel)).read())
+        depth, opens, ends, curly = 0, 0, 0, 0
+        for m in re.finditer(r"[\[\]\(\)\{\}]|\b(function|if|for|while|let|try|struct|type|module|begin|do|quote|macro|end)\b", code):
+            t = m.group(0)
+            if t in "[(":
+                depth += 1
+            elif t in "])":
+                depth -= 1
+                assert depth >= 0, rel
+            elif t == "{":
+                curly += 1
+            elif t == "}":
+                curly -= 1
+                assert curly >= 0, rel
+            elif depth == 0:
+                if t == "end":
+                    ends += 1
+                else:
+                    opens += 1
+        assert depth == 0 and curly == 0, rel
+        assert opens == ends, (rel, opens, ends)
