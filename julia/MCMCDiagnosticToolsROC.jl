@@ -23,7 +23,7 @@ module MCMCDiagnosticToolsROC
 
 using Statistics: Statistics
 
-export ess, rhat, ess_rhat, bulk_tail, rhat_nested, mcse, mcse_rhat_nested, bfmi, gelmandiag, status, shard_bounds, samples_from_chains, UnsupportedOnDevice
+export ess, rhat, ess_rhat, bulk_tail, rhat_nested, mcse, mcse_rhat_nested, bfmi, gelmandiag, status, reserve, shard_bounds, samples_from_chains, UnsupportedOnDevice
 export AbstractAutocovMethod, AutocovMethod, FFTAutocovMethod, BDAAutocovMethod
 
 const libmdt = get(ENV, "MDT_HIP_LIB", "libmdt_hip.so")

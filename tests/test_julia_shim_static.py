@@ -207,3 +207,20 @@ def test_blocks_and_brackets_balance_in_the_julia_sources():
                     opens += 1
         assert depth == 0 and curly == 0, rel
         assert opens == ends, (rel, opens, ends)
+
+
+def test_the_shim_exports_what_the_python_mirror_offers():
+    """the two host mirrors offer the same requests (the Python one is the tested one): every request function of the package is
+    defined and exported by the shim (`rank_normalize` is the Python side's stage output for parity checks, `from_mcmcchains_layout`
+    is `samples_from_chains` there: a view, not a copy)"""
+    jl = _julia_code_only(open(JL).read())
+    exported = set()
+    for m in re.finditer(r"^export (.*)$", jl, flags=re.M):
+        exported |= {t.strip() for t in m.group(1).split(",")}
+    for name in ("ess", "rhat", "ess_rhat", "bulk_tail", "rhat_nested", "mcse", "mcse_rhat_nested", "bfmi", "gelmandiag", "status",
+                 "reserve", "shard_bounds", "AutocovMethod", "FFTAutocovMethod", "BDAAutocovMethod"):
+        assert name in exported, name
+        assert re.search(r"^(function |struct |abstract type )?" + name + r"\b", jl, flags=re.M), name
+    pkg = g.load_package()
+    for name in ("ess", "rhat", "ess_rhat", "bulk_tail", "rhat_nested", "mcse", "mcse_rhat_nested", "bfmi", "gelmandiag", "status", "reserve", "shard_bounds"):
+        assert callable(getattr(pkg, name)), name
