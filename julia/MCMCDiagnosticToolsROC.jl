@@ -211,7 +211,8 @@ function _prepare(x::AbstractArray)
     end
     if _is_device(x)
         eltype(x) === T || throw(ArgumentError("device arrays must be Float32 or Float64"))
-        return Prepared{T,typeof(x)}(reshape(x, size(x, 1), size(x, 2), :), nothing, Int32(1))
+        x3 = reshape(x, size(x, 1), size(x, 2), :)                   # (typeof(x3), not typeof(x): a 2-d or 4-d device array changes rank here)
+        return Prepared{T,typeof(x3)}(x3, nothing, Int32(1))
     end
     xa = collect(x)                                              # drops axes offsets, keeps the memory order
     x3 = reshape(xa, size(xa, 1), size(xa, 2), :)
