@@ -347,6 +347,7 @@ def other_configs(pkg, device, steps, warmup):
         if traffic:
             out[key]["roofline"]["traffic_over_algorithmic"] = traffic["over_algorithmic"]
             out[key]["roofline"]["traffic_source"] = traffic["source"]
+            out[key]["roofline"]["traffic_rate_gbs"] = traffic["bytes_per_launch"] / (out[key]["ms"] * 1e-3) / 1e9
         if issue:
             out[key]["roofline"]["issue"] = issue
     return out
@@ -706,12 +707,21 @@ def main():
         if traffic:
             res["roofline"]["traffic"] = traffic["bytes_per_launch"]
             res["roofline"]["traffic_source"] = traffic["source"]
+            # the same roofline on the bytes the launch really moves (memory side, from the committed counters) over the kernel time
+            # measured HERE: how busy the memory system is, as opposed to how far the algorithm's traffic is from its input size
+            res["roofline"]["traffic_rate"] = {"achieved": traffic["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": traffic["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "note": "memory-side bytes per launch (roofline.traffic) / kernel_ms; a plain copy reaches ~7200 GB/s "
+                                                       "on the same counters; by phase: profiles/r06_pmc_phases_cfg2.txt (the first ranking pass runs at 5700 GB/s)"}
         if issue:
             res["roofline"]["issue"] = issue
             res["roofline"]["limiter_note"] = (
-                "the nominal bound of this scan/sort/reduce path is HBM (SURVEY.md 8d); what limits the launch is vector instruction issue "
-                f"(roofline.issue: {issue['valu_wave_insts']:.3g} vector wave-instructions per launch, floor {issue['floor_ms']:.2f} ms) and dependent "
-                f"LDS / L2 round trips between barriers; counters: profiles/{tj.get('profile')}_counters.txt, phases: DESIGN.md")
+                "the nominal bound of this scan/sort/reduce path is HBM (SURVEY.md 8d).  The launch moves ~12x its input through the memory side "
+                "(roofline.traffic, roofline.traffic_rate: about half of the HBM peak over the whole launch); its first ranking pass is bound by that "
+                "bandwidth (5.7 TB/s where a copy reaches 7.2: profiles/r06_pmc_phases_cfg2.txt), the other phases by dependent LDS / L2 round trips "
+                f"between barriers at four waves per SIMD (vector pipes 56 % busy by SQ_ACTIVE_INST_VALU; roofline.issue: {issue['valu_wave_insts']:.3g} vector "
+                f"wave-instructions per launch, floor {issue['floor_ms']:.2f} ms); counters: profiles/{tj.get('profile')}_counters.txt, "
+                "profiles/r06_instruction_mix.txt, phases: DESIGN.md 5b")
 
         if dry:
             res["dry_run"] = True
